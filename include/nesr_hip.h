@@ -1,0 +1,129 @@
+/*
+ * nesr_hip.h -- C ABI of libnesr_hip.so: the MI355X (gfx950) Real-ESRGAN / RRDBNet inference path.
+ *
+ * The reference (gddickinson/neural_enhanced_super_resolution) is pure Python and has no FFI of
+ * its own; the arithmetic of this path lives in the un-vendored pip packages basicsr (RRDBNet)
+ * and realesrgan (RealESRGANer).  Each entry point below names the reference interface it
+ * stands behind (paths relative to the reference root).  The Python host side
+ * (neural_enhanced_super_resolution_amd/) binds these with ctypes and presents the
+ * RRDBNet / RealESRGANer objects the reference constructs at nesr/nesr.py:216-229 and
+ * standalone/direct_esrgan.py:104-127.
+ *
+ * Conventions: every function returns 0 on success and a negative code on failure; the message
+ * is available from nesr_last_error() (thread-local).  No exception crosses the ABI.  Device
+ * pointers are caller-owned (e.g. torch tensors' data_ptr()); the context owns packed weights
+ * and its workspace.  `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ * device work is enqueued on it asynchronously.  One in-flight call per context
+ * (the reference calls from one thread at a time: main thread or one QThread,
+ * nesr/gui/app.py:72,1732-1749); hipSetDevice is done on entry so any thread may call.
+ */
+#ifndef NESR_HIP_H
+#define NESR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nesr_ctx nesr_ctx;
+
+enum { NESR_DTYPE_F32 = 0, NESR_DTYPE_BF16 = 1 };
+enum { NESR_ROUND_TRUNC = 0, NESR_ROUND_NEAREST = 1 };
+
+enum {
+    NESR_OK = 0,
+    NESR_ERR_ARG = -1,      /* bad argument / unsupported shape */
+    NESR_ERR_HIP = -2,      /* a HIP runtime call failed */
+    NESR_ERR_STATE = -3,    /* weights missing / not finalized */
+    NESR_ERR_NOMEM = -4
+};
+
+/*
+ * Replaces: RRDBNet.__init__ (basicsr archs/rrdbnet_arch.py) as called at nesr/nesr.py:216,
+ * standalone/direct_esrgan.py:104, standalone/superres_project.py:69.
+ *   conv_first_in_ch : input channels of conv_first (3 for x4plus; 12 for x2plus and for the
+ *                      nesr 12-channel quirk)
+ *   unshuffle        : 0 = none (upstream scale=4), 2 = pixel_unshuffle(2) folded into the input
+ *                      load (upstream scale=2), 4 = pixel_unshuffle(4) (upstream scale=1).
+ *                      forward() then expects C = conv_first_in_ch / unshuffle^2 input channels.
+ *   dtype            : arithmetic type of activations/weights (accumulation is always f32).
+ */
+int nesr_create(nesr_ctx** out, int device_id, int conv_first_in_ch, int unshuffle, int num_feat,
+                int num_block, int num_grow_ch, int num_out_ch, int dtype);
+
+/*
+ * Replaces: model.load_state_dict(loadnet[keyname], strict=True) in RealESRGANer.__init__
+ * (realesrgan utils.py), reached from nesr/nesr.py:220-229, standalone/direct_esrgan.py:118-127.
+ * `key` is the upstream state_dict name ("conv_first.weight", "body.0.rdb1.conv1.bias", ...),
+ * `data` a HOST pointer to f32 (weights OIHW, bias [O]); it is repacked and copied, the caller
+ * keeps ownership.  Unknown key or shape mismatch -> NESR_ERR_ARG (strict=True semantics).
+ */
+int nesr_load_weight(nesr_ctx* ctx, const char* key, const float* data, const int64_t* shape, int ndim);
+
+/* strict=True: fails with NESR_ERR_STATE (message lists the first missing keys) unless every
+ * tensor of the architecture was loaded. Uploads packed weights to the device. */
+int nesr_finalize_weights(nesr_ctx* ctx);
+
+/* Number of state_dict tensors the architecture expects (702 for num_block=23). */
+int nesr_num_tensors(const nesr_ctx* ctx);
+
+/*
+ * Replaces: RRDBNet.forward -- `self.model(self.img)` in RealESRGANer.process/tile_process and
+ * `model(img_12ch)` at nesr/nesr.py:891,935.
+ *   x_dev : NCHW f32 [N, C, H, W] contiguous device memory
+ *   y_dev : NCHW f32 [N, num_out_ch, 4*H/u, 4*W/u] (u = unshuffle or 1) device memory
+ * H and W must be multiples of the unshuffle factor (upstream asserts the same).
+ */
+int nesr_forward(nesr_ctx* ctx, const void* x_dev, int N, int C, int H, int W, void* y_dev, void* stream);
+
+/*
+ * Fused image path: replaces `img/255`, cv2 BGR<->RGB flips, HWC->CHW,
+ * RRDBNet.forward, clamp(0,1), x255 and the quantiser of RealESRGANer.enhance
+ * (round_mode NESR_ROUND_NEAREST, flip_rgb 1) or of nesr/nesr.py:851-857,894-901
+ * (NESR_ROUND_TRUNC, flip_rgb 0).
+ *   in_hwc_dev  : u8 [H, W, 3] device memory;  out_hwc_dev : u8 [4H/u, 4W/u, 3] device memory.
+ * Requires conv_first_in_ch / unshuffle^2 == 3 and num_out_ch == 3.
+ */
+int nesr_forward_u8(nesr_ctx* ctx, const uint8_t* in_hwc_dev, int H, int W, uint8_t* out_hwc_dev,
+                    int flip_rgb, int round_mode, void* stream);
+
+/* Device bytes of activation workspace forward() needs for a batch of N frames of H x W input. */
+size_t nesr_workspace_bytes(const nesr_ctx* ctx, int N, int H, int W);
+
+/* Pre-allocates the workspace (forward() grows it on demand otherwise, which synchronises). */
+int nesr_reserve(nesr_ctx* ctx, int N, int H, int W);
+
+/* Algorithmic FLOPs (2 x MACs) of one forward() on N frames of H x W input. */
+double nesr_forward_flops(const nesr_ctx* ctx, int N, int H, int W);
+
+/*
+ * Timing hook for bench.py's roofline leg: when enabled, forward() brackets the dominant kernel
+ * family (the dense-block 3x3 convs) with hipEvents on the caller's stream; nesr_kernel_time_ms
+ * returns the accumulated elapsed ms and launch count since the last call (synchronises those
+ * events).  Off by default.
+ */
+int nesr_set_kernel_timing(nesr_ctx* ctx, int enable);
+int nesr_kernel_time_ms(nesr_ctx* ctx, double* total_ms, int64_t* launches, double* flops);
+
+void nesr_destroy(nesr_ctx* ctx);
+
+/*
+ * Single-layer entry (test hook for the per-layer parity tests): one 3x3 stride-1 zero-pad-1
+ * convolution + bias (+ LeakyReLU(0.2) if lrelu) (+ nearest x2 upsample of the input first if
+ * upsample), i.e. torch.nn.Conv2d / F.leaky_relu / F.interpolate as composed in RRDBNet.forward.
+ *   x_dev NCHW f32 [N,Cin,H,W];  w_host OIHW f32 [Cout,Cin,3,3];  b_host [Cout];
+ *   y_dev NCHW f32 [N,Cout,H<<upsample,W<<upsample].  Synchronous.
+ */
+int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, int H, int W,
+                 const float* w_host, const float* b_host, int Cout, int lrelu, int upsample,
+                 void* y_dev, void* stream);
+
+const char* nesr_last_error(void);
+const char* nesr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NESR_HIP_H */

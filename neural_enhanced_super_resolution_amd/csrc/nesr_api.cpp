@@ -1,0 +1,536 @@
+// C ABI of libnesr_hip.so (include/nesr_hip.h): context, strict weight loading + repacking,
+// workspace, and the RRDBNet forward graph as a sequence of fused conv launches.
+//
+// What it stands behind in the reference: basicsr RRDBNet.__init__/forward and realesrgan
+// RealESRGANer's load_state_dict, as called from nesr/nesr.py:216-229,887-891 and
+// standalone/direct_esrgan.py:104-148.
+#include "../../include/nesr_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "nesr_kernels.h"
+
+using namespace nesr;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return fail(NESR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));   \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int round_up(int v, int a) { return (v + a - 1) / a * a; }
+
+struct Layer {
+    std::string name;
+    int cin = 0, cout = 0, cin_p = 0, cout_p = 0;
+    std::vector<float> w, b;  // host copies until finalize
+    bool has_w = false, has_b = false;
+    void* d_w = nullptr;
+    float* d_b = nullptr;
+};
+
+}  // namespace
+
+struct nesr_ctx {
+    int device = 0, cin0 = 3, unshuffle = 0, nf = 64, nb = 23, gc = 32, nout = 3, dtype = 0;
+    int kgroup = 8;  // K-group of the conv kernel: cin padding granule
+    std::vector<Layer> layers;
+    std::unordered_map<std::string, int> index;
+    bool finalized = false;
+    char* d_weights = nullptr;
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    // kernel timing hook
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
+    int64_t timed_launches = 0;
+    double timed_flops = 0.0;
+
+    size_t esize() const { return dtype == NESR_DTYPE_BF16 ? 2 : 4; }
+    int ct() const { return nf + 4 * gc; }  // channels of a dense-block buffer
+    int ufac() const { return unshuffle > 1 ? unshuffle : 1; }
+};
+
+namespace {
+
+int layer_id(const nesr_ctx* c, int b, int r, int k) { return 1 + (b * 3 + r) * 5 + k; }  // r,k zero based
+
+struct WsLayout {
+    size_t in, f, a, b, c, u1, u2, u3, total;
+};
+
+WsLayout ws_layout(const nesr_ctx* c, int N, int h, int w) {
+    const size_t es = c->esize();
+    const size_t px = (size_t)N * h * w;
+    WsLayout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    };
+    L.in = take(px * c->layers[0].cin_p * es);
+    L.f = take(px * c->nf * es);
+    L.a = take(px * c->ct() * es);
+    L.b = take(px * c->ct() * es);
+    L.c = take(px * c->ct() * es);
+    L.u1 = take(px * 4 * c->nf * es);
+    L.u2 = take(px * 16 * c->nf * es);
+    L.u3 = take(px * 16 * c->nf * es);
+    L.total = off;
+    return L;
+}
+
+int ensure_ws(nesr_ctx* c, size_t bytes) {
+    if (bytes <= c->ws_bytes) return NESR_OK;
+    if (c->ws) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(c->ws));
+        c->ws = nullptr;
+        c->ws_bytes = 0;
+    }
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(NESR_ERR_NOMEM, "hipMalloc(workspace " + std::to_string(bytes) + " B): " + hipGetErrorString(e));
+    c->ws = static_cast<char*>(p);
+    c->ws_bytes = bytes;
+    return NESR_OK;
+}
+
+hipError_t launch_conv(const nesr_ctx* c, const ConvArgs& a, hipStream_t s) {
+    return c->dtype == NESR_DTYPE_BF16 ? launch_conv3x3_bf16(a, s) : launch_conv3x3_f32(a, s);
+}
+
+ConvArgs base_args(const Layer& L, int N, int h, int w) {
+    ConvArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.cin = L.cin_p;
+    a.w = L.d_w;
+    a.bias = L.d_b;
+    a.coutp = L.cout_p;
+    a.n = N;
+    a.h = h;
+    a.w_ = w;
+    a.in_h = h;
+    a.in_w = w;
+    a.s1 = a.s2 = 1.f;
+    a.cout_real = 0;
+    return a;
+}
+
+double conv_flops(const Layer& L, double pixels) { return 2.0 * 9.0 * L.cin * L.cout * pixels; }
+
+// The forward graph.  x -> y; exactly one of (x_f32, x_u8) and one of (y_f32, y_u8) is set.
+int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, int N, int C, int H, int W,
+                float* y_f32, uint8_t* y_u8, int round_mode, hipStream_t s) {
+    if (!c->finalized) return fail(NESR_ERR_STATE, "weights not finalized (call nesr_finalize_weights)");
+    const int u = c->ufac();
+    if (N <= 0 || H <= 0 || W <= 0) return fail(NESR_ERR_ARG, "empty input");
+    if (C * u * u != c->cin0)
+        return fail(NESR_ERR_ARG, "input has " + std::to_string(C) + " channels; conv_first expects " +
+                                      std::to_string(c->cin0) + " after unshuffle " + std::to_string(u));
+    if (H % u || W % u) return fail(NESR_ERR_ARG, "H and W must be multiples of the unshuffle factor");
+    HIP_TRY(hipSetDevice(c->device));
+    const int h = H / u, w = W / u;
+    const WsLayout L = ws_layout(c, N, h, w);
+    int rc = ensure_ws(c, L.total);
+    if (rc) return rc;
+    char* ws = c->ws;
+    const int nf = c->nf, gc = c->gc, ct = c->ct();
+    const bool bf = c->dtype == NESR_DTYPE_BF16;
+
+    PackArgs p;
+    std::memset(&p, 0, sizeof(p));
+    p.src = x_u8 ? static_cast<const void*>(x_u8) : static_cast<const void*>(x_f32);
+    p.src_u8 = x_u8 ? 1 : 0;
+    p.flip = flip;
+    p.n = N; p.c = C; p.hin = H; p.win = W;
+    p.unshuffle = u;
+    p.dst = ws + L.in;
+    p.cp = c->layers[0].cin_p;
+    p.bf16 = bf;
+    HIP_TRY(launch_pack_input(p, s));
+
+    // conv_first: IN -> A.x0 and F (feat is needed again after the trunk)
+    {
+        ConvArgs a = base_args(c->layers[0], N, h, w);
+        a.in = ws + L.in; a.in_stride = c->layers[0].cin_p;
+        a.out = ws + L.a; a.out_stride = ct; a.out_coff = 0;
+        a.out2 = ws + L.f; a.out2_stride = nf;
+        HIP_TRY(launch_conv(c, a, s));
+    }
+
+    // trunk: 23 x RRDB.  Buffers P,Q,R hold x0|x1|x2|x3|x4 of RDB1,2,3; RDB3's conv5 applies both
+    // residuals (x5*0.2+x0 then *0.2 + RRDB input) and lands in P.x0 in place, so every RRDB
+    // starts and ends in P.
+    char* buf[3] = {ws + L.a, ws + L.b, ws + L.c};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (c->timing) {
+        if (!c->ev_free.empty()) {
+            ev0 = c->ev_free.back().first; ev1 = c->ev_free.back().second;
+            c->ev_free.pop_back();
+        } else {
+            HIP_TRY(hipEventCreate(&ev0));
+            HIP_TRY(hipEventCreate(&ev1));
+        }
+        HIP_TRY(hipEventRecord(ev0, s));
+    }
+    const double px = (double)N * h * w;
+    for (int b = 0; b < c->nb; ++b) {
+        for (int r = 0; r < 3; ++r) {
+            char* cur = buf[r];
+            for (int k = 0; k < 4; ++k) {
+                const Layer& Ly = c->layers[layer_id(c, b, r, k)];
+                ConvArgs a = base_args(Ly, N, h, w);
+                a.in = cur; a.in_stride = ct;
+                a.out = cur; a.out_stride = ct; a.out_coff = nf + k * gc;
+                a.lrelu = 1;
+                HIP_TRY(launch_conv(c, a, s));
+                if (c->timing) c->timed_flops += conv_flops(Ly, px);
+            }
+            const Layer& L5 = c->layers[layer_id(c, b, r, 4)];
+            ConvArgs a = base_args(L5, N, h, w);
+            a.in = cur; a.in_stride = ct;
+            a.res1 = cur; a.res1_stride = ct; a.s1 = 0.2f;
+            if (r < 2) {
+                a.out = buf[r + 1];
+            } else {
+                a.out = buf[0];
+                a.res2 = buf[0]; a.res2_stride = ct; a.s2 = 0.2f;
+            }
+            a.out_stride = ct; a.out_coff = 0;
+            HIP_TRY(launch_conv(c, a, s));
+            if (c->timing) c->timed_flops += conv_flops(L5, px);
+        }
+    }
+    if (c->timing) {
+        HIP_TRY(hipEventRecord(ev1, s));
+        c->ev_pending.emplace_back(ev0, ev1);
+        c->timed_launches += (int64_t)c->nb * 15;
+    }
+
+    const int tail = 1 + c->nb * 15;
+    // feat = feat + conv_body(trunk)   (in place on F)
+    {
+        ConvArgs a = base_args(c->layers[tail], N, h, w);
+        a.in = buf[0]; a.in_stride = ct;
+        a.out = ws + L.f; a.out_stride = nf;
+        a.res1 = ws + L.f; a.res1_stride = nf; a.s1 = 1.0f;
+        HIP_TRY(launch_conv(c, a, s));
+    }
+    // lrelu(conv_up1(nearest2x(feat)))
+    {
+        ConvArgs a = base_args(c->layers[tail + 1], N, 2 * h, 2 * w);
+        a.in = ws + L.f; a.in_stride = nf; a.in_h = h; a.in_w = w; a.up = 1;
+        a.out = ws + L.u1; a.out_stride = nf; a.lrelu = 1;
+        HIP_TRY(launch_conv(c, a, s));
+    }
+    // lrelu(conv_up2(nearest2x(feat)))
+    {
+        ConvArgs a = base_args(c->layers[tail + 2], N, 4 * h, 4 * w);
+        a.in = ws + L.u1; a.in_stride = nf; a.in_h = 2 * h; a.in_w = 2 * w; a.up = 1;
+        a.out = ws + L.u2; a.out_stride = nf; a.lrelu = 1;
+        HIP_TRY(launch_conv(c, a, s));
+    }
+    // lrelu(conv_hr(feat))
+    {
+        ConvArgs a = base_args(c->layers[tail + 3], N, 4 * h, 4 * w);
+        a.in = ws + L.u2; a.in_stride = nf;
+        a.out = ws + L.u3; a.out_stride = nf; a.lrelu = 1;
+        HIP_TRY(launch_conv(c, a, s));
+    }
+    // conv_last -> planar f32 NCHW, or clamped + quantised u8 HWC
+    {
+        ConvArgs a = base_args(c->layers[tail + 4], N, 4 * h, 4 * w);
+        a.in = ws + L.u3; a.in_stride = nf;
+        a.cout_real = c->nout;
+        a.out_nchw = y_f32;
+        a.out_u8 = y_u8;
+        a.u8_flip = flip;
+        a.u8_round = round_mode;
+        HIP_TRY(launch_conv(c, a, s));
+    }
+    return NESR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* nesr_last_error(void) { return g_err.c_str(); }
+const char* nesr_version(void) { return "nesr_hip 0.1 (gfx950)"; }
+
+int nesr_create(nesr_ctx** out, int device_id, int conv_first_in_ch, int unshuffle, int num_feat, int num_block,
+                int num_grow_ch, int num_out_ch, int dtype) {
+    if (!out) return fail(NESR_ERR_ARG, "out is null");
+    *out = nullptr;
+    if (unshuffle != 0 && unshuffle != 1 && unshuffle != 2 && unshuffle != 4)
+        return fail(NESR_ERR_ARG, "unshuffle must be 0, 2 or 4");
+    const int u = unshuffle > 1 ? unshuffle : 1;
+    if (conv_first_in_ch <= 0 || conv_first_in_ch % (u * u))
+        return fail(NESR_ERR_ARG, "conv_first_in_ch must be a positive multiple of unshuffle^2");
+    if (num_feat != 32 && num_feat != 64) return fail(NESR_ERR_ARG, "num_feat must be 32 or 64 (reference uses 64)");
+    if (num_grow_ch != 32) return fail(NESR_ERR_ARG, "num_grow_ch must be 32 (reference uses 32)");
+    if (num_block < 0 || num_out_ch <= 0 || num_out_ch > 32) return fail(NESR_ERR_ARG, "bad num_block / num_out_ch");
+    if (dtype != NESR_DTYPE_F32 && dtype != NESR_DTYPE_BF16) return fail(NESR_ERR_ARG, "dtype must be 0 (f32) or 1 (bf16)");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(NESR_ERR_ARG, "no such device " + std::to_string(device_id));
+    nesr_ctx* c = new nesr_ctx();
+    c->device = device_id;
+    c->cin0 = conv_first_in_ch;
+    c->unshuffle = unshuffle;
+    c->nf = num_feat;
+    c->nb = num_block;
+    c->gc = num_grow_ch;
+    c->nout = num_out_ch;
+    c->dtype = dtype;
+    c->kgroup = dtype == NESR_DTYPE_BF16 ? 16 : 8;
+    auto add = [&](const std::string& name, int cin, int cout) {
+        Layer L;
+        L.name = name;
+        L.cin = cin;
+        L.cout = cout;
+        L.cin_p = round_up(cin, c->kgroup);
+        L.cout_p = round_up(cout, 32);
+        c->index[name] = (int)c->layers.size();
+        c->layers.push_back(std::move(L));
+    };
+    add("conv_first", c->cin0, c->nf);
+    for (int b = 0; b < c->nb; ++b)
+        for (int r = 1; r <= 3; ++r) {
+            const std::string pre = "body." + std::to_string(b) + ".rdb" + std::to_string(r) + ".conv";
+            for (int k = 1; k <= 4; ++k) add(pre + std::to_string(k), c->nf + (k - 1) * c->gc, c->gc);
+            add(pre + "5", c->nf + 4 * c->gc, c->nf);
+        }
+    add("conv_body", c->nf, c->nf);
+    add("conv_up1", c->nf, c->nf);
+    add("conv_up2", c->nf, c->nf);
+    add("conv_hr", c->nf, c->nf);
+    add("conv_last", c->nf, c->nout);
+    *out = c;
+    return NESR_OK;
+}
+
+int nesr_num_tensors(const nesr_ctx* c) { return c ? (int)c->layers.size() * 2 : 0; }
+
+int nesr_load_weight(nesr_ctx* c, const char* key, const float* data, const int64_t* shape, int ndim) {
+    if (!c || !key || !data || !shape) return fail(NESR_ERR_ARG, "null argument");
+    std::string k(key);
+    const size_t dot = k.rfind('.');
+    if (dot == std::string::npos) return fail(NESR_ERR_ARG, "unexpected key in state_dict: " + k);
+    const std::string lname = k.substr(0, dot), kind = k.substr(dot + 1);
+    auto it = c->index.find(lname);
+    if (it == c->index.end() || (kind != "weight" && kind != "bias"))
+        return fail(NESR_ERR_ARG, "unexpected key in state_dict: " + k);
+    Layer& L = c->layers[it->second];
+    if (kind == "weight") {
+        if (ndim != 4 || shape[0] != L.cout || shape[1] != L.cin || shape[2] != 3 || shape[3] != 3)
+            return fail(NESR_ERR_ARG, "size mismatch for " + k + ": expected [" + std::to_string(L.cout) + "," +
+                                          std::to_string(L.cin) + ",3,3]");
+        L.w.assign(data, data + (size_t)L.cout * L.cin * 9);
+        L.has_w = true;
+    } else {
+        if (ndim != 1 || shape[0] != L.cout)
+            return fail(NESR_ERR_ARG, "size mismatch for " + k + ": expected [" + std::to_string(L.cout) + "]");
+        L.b.assign(data, data + L.cout);
+        L.has_b = true;
+    }
+    c->finalized = false;
+    return NESR_OK;
+}
+
+int nesr_finalize_weights(nesr_ctx* c) {
+    if (!c) return fail(NESR_ERR_ARG, "null ctx");
+    std::string missing;
+    int nmiss = 0;
+    for (const Layer& L : c->layers) {
+        if (!L.has_w && nmiss++ < 4) missing += " " + L.name + ".weight";
+        if (!L.has_b && nmiss++ < 4) missing += " " + L.name + ".bias";
+    }
+    if (nmiss) return fail(NESR_ERR_STATE, "Missing key(s) in state_dict (" + std::to_string(nmiss) + "):" + missing);
+    HIP_TRY(hipSetDevice(c->device));
+    const bool bf = c->dtype == NESR_DTYPE_BF16;
+    size_t total = 0;
+    std::vector<size_t> woff(c->layers.size()), boff(c->layers.size());
+    for (size_t i = 0; i < c->layers.size(); ++i) {
+        const Layer& L = c->layers[i];
+        const size_t we = bf ? packed_weight_elems_bf16(L.cin_p, L.cout_p) : packed_weight_elems_f32(L.cin_p, L.cout_p);
+        woff[i] = total;
+        total = align_up(total + we * (bf ? 2 : 4), 256);
+        boff[i] = total;
+        total = align_up(total + (size_t)L.cout_p * 4, 256);
+    }
+    std::vector<char> host(total, 0);
+    for (size_t i = 0; i < c->layers.size(); ++i) {
+        const Layer& L = c->layers[i];
+        if (bf)
+            pack_weights_bf16(L.w.data(), L.cout, L.cin, L.cin_p, L.cout_p, reinterpret_cast<uint16_t*>(host.data() + woff[i]));
+        else
+            pack_weights_f32(L.w.data(), L.cout, L.cin, L.cin_p, L.cout_p, reinterpret_cast<float*>(host.data() + woff[i]));
+        std::memcpy(host.data() + boff[i], L.b.data(), (size_t)L.cout * 4);
+    }
+    if (c->d_weights) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipFree(c->d_weights));
+        c->d_weights = nullptr;
+    }
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, total));
+    c->d_weights = static_cast<char*>(p);
+    HIP_TRY(hipMemcpy(c->d_weights, host.data(), total, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < c->layers.size(); ++i) {
+        c->layers[i].d_w = c->d_weights + woff[i];
+        c->layers[i].d_b = reinterpret_cast<float*>(c->d_weights + boff[i]);
+    }
+    c->finalized = true;
+    return NESR_OK;
+}
+
+int nesr_forward(nesr_ctx* c, const void* x_dev, int N, int C, int H, int W, void* y_dev, void* stream) {
+    if (!c || !x_dev || !y_dev) return fail(NESR_ERR_ARG, "null argument");
+    return run_forward(c, static_cast<const float*>(x_dev), nullptr, 0, N, C, H, W, static_cast<float*>(y_dev), nullptr, 0,
+                       static_cast<hipStream_t>(stream));
+}
+
+int nesr_forward_u8(nesr_ctx* c, const uint8_t* in_hwc_dev, int H, int W, uint8_t* out_hwc_dev, int flip_rgb,
+                    int round_mode, void* stream) {
+    if (!c || !in_hwc_dev || !out_hwc_dev) return fail(NESR_ERR_ARG, "null argument");
+    const int u = c->ufac();
+    if (c->cin0 != 3 * u * u || c->nout != 3)
+        return fail(NESR_ERR_ARG, "nesr_forward_u8 needs a 3-channel-in / 3-channel-out network");
+    return run_forward(c, nullptr, in_hwc_dev, flip_rgb ? 1 : 0, 1, 3, H, W, nullptr, out_hwc_dev,
+                       round_mode == NESR_ROUND_NEAREST ? 1 : 0, static_cast<hipStream_t>(stream));
+}
+
+size_t nesr_workspace_bytes(const nesr_ctx* c, int N, int H, int W) {
+    if (!c || N <= 0 || H <= 0 || W <= 0) return 0;
+    const int u = c->ufac();
+    return ws_layout(c, N, (H + u - 1) / u, (W + u - 1) / u).total;
+}
+
+int nesr_reserve(nesr_ctx* c, int N, int H, int W) {
+    if (!c) return fail(NESR_ERR_ARG, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    return ensure_ws(c, nesr_workspace_bytes(c, N, H, W));
+}
+
+double nesr_forward_flops(const nesr_ctx* c, int N, int H, int W) {
+    if (!c) return 0.0;
+    const int u = c->ufac();
+    const double px = (double)N * (H / u) * (W / u);
+    double f = 0.0;
+    const int tail = 1 + c->nb * 15;
+    for (int i = 0; i < (int)c->layers.size(); ++i) {
+        double scale = 1.0;
+        if (i == tail + 1) scale = 4.0;
+        if (i >= tail + 2) scale = 16.0;
+        f += conv_flops(c->layers[i], px * scale);
+    }
+    return f;
+}
+
+int nesr_set_kernel_timing(nesr_ctx* c, int enable) {
+    if (!c) return fail(NESR_ERR_ARG, "null ctx");
+    c->timing = enable != 0;
+    return NESR_OK;
+}
+
+int nesr_kernel_time_ms(nesr_ctx* c, double* total_ms, int64_t* launches, double* flops) {
+    if (!c) return fail(NESR_ERR_ARG, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    double ms = 0.0;
+    for (auto& pr : c->ev_pending) {
+        HIP_TRY(hipEventSynchronize(pr.second));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, pr.first, pr.second));
+        ms += t;
+        c->ev_free.push_back(pr);
+    }
+    c->ev_pending.clear();
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = c->timed_launches;
+    if (flops) *flops = c->timed_flops;
+    c->timed_launches = 0;
+    c->timed_flops = 0.0;
+    return NESR_OK;
+}
+
+void nesr_destroy(nesr_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto& pr : c->ev_pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto& pr : c->ev_free) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->d_weights) (void)hipFree(c->d_weights);
+    delete c;
+}
+
+int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, int H, int W, const float* w_host,
+                 const float* b_host, int Cout, int lrelu, int upsample, void* y_dev, void* stream) {
+    if (!x_dev || !w_host || !b_host || !y_dev) return fail(NESR_ERR_ARG, "null argument");
+    if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout > 64) return fail(NESR_ERR_ARG, "bad shape (Cout <= 64)");
+    if (dtype != NESR_DTYPE_F32 && dtype != NESR_DTYPE_BF16) return fail(NESR_ERR_ARG, "bad dtype");
+    HIP_TRY(hipSetDevice(device_id));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool bf = dtype == NESR_DTYPE_BF16;
+    const size_t es = bf ? 2 : 4;
+    const int cin_p = round_up(Cin, bf ? 16 : 8), cout_p = round_up(Cout, 32);
+    const int up = upsample ? 1 : 0;
+    const int ho = H << up, wo = W << up;
+    const size_t we = bf ? packed_weight_elems_bf16(cin_p, cout_p) : packed_weight_elems_f32(cin_p, cout_p);
+    std::vector<char> hw(we * es);
+    if (bf)
+        pack_weights_bf16(w_host, Cout, Cin, cin_p, cout_p, reinterpret_cast<uint16_t*>(hw.data()));
+    else
+        pack_weights_f32(w_host, Cout, Cin, cin_p, cout_p, reinterpret_cast<float*>(hw.data()));
+    std::vector<float> hb(cout_p, 0.f);
+    std::memcpy(hb.data(), b_host, (size_t)Cout * 4);
+    char *d_w = nullptr, *d_in = nullptr, *d_out = nullptr;
+    float* d_b = nullptr;
+    const size_t in_bytes = (size_t)N * H * W * cin_p * es, out_bytes = (size_t)N * ho * wo * cout_p * es;
+    HIP_TRY(hipMalloc((void**)&d_w, hw.size()));
+    HIP_TRY(hipMalloc((void**)&d_b, hb.size() * 4));
+    HIP_TRY(hipMalloc((void**)&d_in, in_bytes));
+    HIP_TRY(hipMalloc((void**)&d_out, out_bytes));
+    HIP_TRY(hipMemcpy(d_w, hw.data(), hw.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    PackArgs p;
+    std::memset(&p, 0, sizeof(p));
+    p.src = x_dev; p.n = N; p.c = Cin; p.hin = H; p.win = W; p.unshuffle = 1; p.dst = d_in; p.cp = cin_p; p.bf16 = bf;
+    HIP_TRY(launch_pack_input(p, s));
+    ConvArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = d_in; a.in_stride = cin_p; a.in_h = H; a.in_w = W; a.up = up; a.cin = cin_p;
+    a.w = d_w; a.bias = d_b; a.coutp = cout_p;
+    a.n = N; a.h = ho; a.w_ = wo;
+    a.out = d_out; a.out_stride = cout_p; a.out_coff = 0;
+    a.lrelu = lrelu ? 1 : 0; a.s1 = a.s2 = 1.f;
+    HIP_TRY(bf ? launch_conv3x3_bf16(a, s) : launch_conv3x3_f32(a, s));
+    HIP_TRY(launch_nhwc_to_nchw(d_out, bf, cout_p, N, Cout, ho, wo, static_cast<float*>(y_dev), s));
+    HIP_TRY(hipStreamSynchronize(s));
+    (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_in); (void)hipFree(d_out);
+    return NESR_OK;
+}
+
+}  // extern "C"

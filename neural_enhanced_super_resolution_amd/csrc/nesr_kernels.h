@@ -1,0 +1,70 @@
+// Internal launcher interface between the C-ABI layer (nesr_api.cpp) and the HIP kernels.
+// Not part of the public ABI (that is include/nesr_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nesr {
+
+// One fused 3x3 / stride 1 / zero-pad 1 convolution over NHWC activations
+// (feature maps are NHWC; an RDB owns one 192-channel buffer whose channel
+// slices are x0|x1|x2|x3|x4, so torch.cat disappears).
+struct ConvArgs {
+    // input: NHWC, `in_stride` elements between pixels, channels [0, cin) are read.
+    const void* in;
+    int in_stride;
+    int in_h, in_w;        // stored (source) height/width
+    int up;                // 1: the logical input is the nearest x2 upsample of the stored one
+                           //    (F.interpolate(scale_factor=2, mode='nearest') folded into addressing)
+    int cin;               // padded to a multiple of the kernel's K-group (8 for f32, 16 for bf16)
+    // packed weights / bias (device)
+    const void* w;
+    const float* bias;     // [coutp] f32
+    int coutp;             // padded output channels: 32 or 64
+    // geometry of the convolution (logical input == output spatial size)
+    int n, h, w_;
+    // NHWC output (may be null when out_nchw / out_u8 is used)
+    void* out;
+    int out_stride, out_coff;
+    void* out2;            // optional second copy of the same values (channels [0,coutp))
+    int out2_stride;
+    // epilogue: v = acc + bias; if lrelu v = leaky(v, 0.2); if res1 v = v*s1 + res1; if res2 v = v*s2 + res2
+    int lrelu;
+    const void* res1; int res1_stride; float s1;
+    const void* res2; int res2_stride; float s2;
+    // planar f32 output [n][cout_real][h][w] (conv_last feeding RRDBNet.forward's NCHW result)
+    float* out_nchw;
+    int cout_real;
+    // fused image output: u8 HWC [h][w][3], clamp(0,1) * 255, optional channel flip
+    uint8_t* out_u8;
+    int u8_flip, u8_round;
+};
+
+// f32 path: v_mfma_f32_32x32x2_f32 implicit GEMM (conv3x3_f32.hip)
+hipError_t launch_conv3x3_f32(const ConvArgs& a, hipStream_t s);
+// host-side weight repack for the f32 kernel: OIHW f32 -> [cin/8][tap][half][coutp][4]
+size_t packed_weight_elems_f32(int cin_p, int coutp);
+void pack_weights_f32(const float* oihw, int cout, int cin, int cin_p, int coutp, float* dst);
+
+// bf16 path: v_mfma_f32_32x32x16_bf16 implicit GEMM (conv3x3_bf16.hip)
+hipError_t launch_conv3x3_bf16(const ConvArgs& a, hipStream_t s);
+size_t packed_weight_elems_bf16(int cin_p, int coutp);
+void pack_weights_bf16(const float* oihw, int cout, int cin, int cin_p, int coutp, uint16_t* dst);
+
+// input packers (pack.hip): NCHW f32 (+ pixel_unshuffle) -> NHWC with `cp` channels (zero padded)
+struct PackArgs {
+    const void* src;     // f32 NCHW [n][c][hin][win]   or u8 HWC [hin][win][3] (n == 1)
+    int src_u8;          // 1: u8 HWC source, value/255, optional channel flip
+    int flip;
+    int n, c, hin, win;
+    int unshuffle;       // 1, 2 or 4
+    void* dst;           // NHWC [n][hin/u][win/u][cp]
+    int cp;
+    int bf16;            // destination element type
+};
+hipError_t launch_pack_input(const PackArgs& a, hipStream_t s);
+
+// NHWC (stride, channels [0,c)) -> planar f32 NCHW; used by the single-layer test hook
+hipError_t launch_nhwc_to_nchw(const void* src, int bf16, int stride, int n, int c, int h, int w, float* dst, hipStream_t s);
+
+}  // namespace nesr

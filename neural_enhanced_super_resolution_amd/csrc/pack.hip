@@ -1,0 +1,86 @@
+// Layout kernels at the edges of the network (HBM-bound, one pass each).
+//
+// pack_input: RRDBNet.forward's `pixel_unshuffle(x, scale)` (basicsr arch_util:
+//   x.view(b,c,h,s,w,s).permute(0,1,3,5,2,4) -> channel index c*s*s + sy*s + sx) fused with the
+//   NCHW -> NHWC change of layout and the zero padding of conv_first's input channels to the
+//   kernel's K-group.  With a u8 HWC source it also performs RealESRGANer.enhance's
+//   `img.astype(float32) / 255` and the BGR->RGB flip (cv2.cvtColor), or nesr/nesr.py:851-857
+//   (no flip).
+#include <hip/hip_bf16.h>
+
+#include "nesr_kernels.h"
+
+namespace nesr {
+namespace {
+
+__device__ inline uint16_t f2bf(float f) {
+    __hip_bfloat16 b = __float2bfloat16(f);
+    return *reinterpret_cast<uint16_t*>(&b);
+}
+__device__ inline float bf2f(uint16_t u) { return __uint_as_float(((unsigned)u) << 16); }
+
+__global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
+    const int s = a.unshuffle;
+    const int ho = a.hin / s, wo = a.win / s;
+    const size_t total = (size_t)a.n * ho * wo;
+    for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(pix % wo);
+        const int y = (int)((pix / wo) % ho);
+        const int n = (int)(pix / ((size_t)wo * ho));
+        for (int co = 0; co < a.cp; ++co) {
+            float v = 0.f;
+            const int c = co / (s * s);
+            if (c < a.c) {
+                const int r = co - c * s * s;
+                const int sy = r / s, sx = r - sy * s;
+                const int Y = y * s + sy, X = x * s + sx;
+                if (a.src_u8) {
+                    const int cs = a.flip ? (a.c - 1 - c) : c;
+                    const uint8_t* src = static_cast<const uint8_t*>(a.src);
+                    v = (float)src[(((size_t)n * a.hin + Y) * a.win + X) * a.c + cs] / 255.0f;
+                } else {
+                    const float* src = static_cast<const float*>(a.src);
+                    v = src[(((size_t)n * a.c + c) * a.hin + Y) * a.win + X];
+                }
+            }
+            if (a.bf16)
+                static_cast<uint16_t*>(a.dst)[pix * a.cp + co] = f2bf(v);
+            else
+                static_cast<float*>(a.dst)[pix * a.cp + co] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* src, int bf16, int stride, int n, int c, int h, int w, float* dst) {
+    const size_t total = (size_t)n * c * h * w;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w);
+        const int y = (int)((i / w) % h);
+        const int ch = (int)((i / ((size_t)w * h)) % c);
+        const int nn = (int)(i / ((size_t)w * h * c));
+        const size_t pix = ((size_t)nn * h + y) * w + x;
+        dst[i] = bf16 ? bf2f(static_cast<const uint16_t*>(src)[pix * stride + ch]) : static_cast<const float*>(src)[pix * stride + ch];
+    }
+}
+
+}  // namespace
+
+hipError_t launch_pack_input(const PackArgs& a, hipStream_t s) {
+    const size_t total = (size_t)a.n * (a.hin / a.unshuffle) * (a.win / a.unshuffle);
+    if (total == 0) return hipSuccess;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pack_input_kernel, dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_nhwc_to_nchw(const void* src, int bf16, int stride, int n, int c, int h, int w, float* dst, hipStream_t s) {
+    const size_t total = (size_t)n * c * h * w;
+    if (total == 0) return hipSuccess;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks), dim3(256), 0, s, src, bf16, stride, n, c, h, w, dst);
+    return hipGetLastError();
+}
+
+}  // namespace nesr

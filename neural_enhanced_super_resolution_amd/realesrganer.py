@@ -1,0 +1,281 @@
+"""``RealESRGANer`` drop-in: same constructor keywords, attributes and methods as
+``realesrgan.RealESRGANer`` (realesrgan>=0.3.0, requirements.txt:9), as the reference uses it:
+
+  nesr/nesr.py:220-229                   RealESRGANer(scale=int(upscale_factor), model_path=..., model=model,
+                                         tile=0, tile_pad=0, pre_pad=0, half=False, device=self.device);
+                                         afterwards only ``.model`` is used (nesr/nesr.py:887-891,930-935)
+  standalone/direct_esrgan.py:118-127    RealESRGANer(scale, model_path, model, tile=512, tile_pad=10,
+                                         pre_pad=0, half=False, device) ; ``.enhance(img)`` at :148
+  standalone/superres_project.py:70-75   ctor defaults ; ``.enhance(bgr)`` at :282
+
+Host logic only (padding, tile grid, cropping, colour order, quantisation); every network
+evaluation goes through ``self.model``, which for this package is the HIP-backed
+:class:`RRDBNet`.  cv2 is optional: the colour conversions are plain numpy; only
+``outscale != scale`` and ``alpha_upsampler != 'realesrgan'`` need cv2.resize.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+
+import numpy as np
+import torch
+from torch.nn import functional as F
+
+from .rrdbnet import RRDBNet
+
+
+def _bgr2gray(img):
+    # cv2.COLOR_BGR2GRAY on float32
+    return (img[..., 0] * np.float32(0.114) + img[..., 1] * np.float32(0.587) + img[..., 2] * np.float32(0.299)).astype(np.float32)
+
+
+def _gray2rgb(img):
+    return np.repeat(img[:, :, None], 3, axis=2)
+
+
+class RealESRGANer:
+    """A helper class for upsampling images with RealESRGAN (MI355X/HIP backend).
+
+    Args:
+        scale (int): Upsampling scale factor used in the networks. It is usually 2 or 4.
+        model_path (str | list[str] | dict): checkpoint path(s) ({'params_ema'|'params': state_dict}),
+            or an already loaded checkpoint dict.
+        dni_weight (list[float]): deep-network-interpolation weights when model_path is a list of two.
+        model (nn.Module): the network (RRDBNet).
+        tile (int): tile size; 0 = no tiling.
+        tile_pad (int): pad size of each tile.  pre_pad (int): reflect pad before the network.
+        half (bool): upstream's fp16 switch; here it selects the bf16 MFMA kernels.
+        device: 'cuda' (= the ROCm GPU), torch.device or None (-> cuda if available).
+    """
+
+    def __init__(self, scale, model_path, dni_weight=None, model=None, tile=0, tile_pad=10, pre_pad=10,
+                 half=False, device=None, gpu_id=None):
+        self.scale = scale
+        self.tile_size = tile
+        self.tile_pad = tile_pad
+        self.pre_pad = pre_pad
+        self.mod_scale = None
+        self.half = half
+        self.tile_batch = 8   # equal-shaped tiles evaluated per forward call (1 = upstream's serial loop)
+
+        if gpu_id:
+            self.device = torch.device(f"cuda:{gpu_id}" if torch.cuda.is_available() else "cpu") if device is None else device
+        else:
+            self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu") if device is None else device
+        self.device = torch.device(self.device)
+
+        if isinstance(model_path, list):
+            assert len(model_path) == len(dni_weight), "model_path and dni_weight should have the save length."
+            loadnet = self.dni(model_path[0], model_path[1], dni_weight)
+        elif isinstance(model_path, dict):
+            loadnet = model_path
+        else:
+            if str(model_path).startswith("https://"):
+                raise RuntimeError(f"{model_path}: downloading checkpoints is not supported (offline build); "
+                                   "pass a local path to RealESRGAN_x2plus.pth / RealESRGAN_x4plus.pth")
+            loadnet = torch.load(model_path, map_location=torch.device("cpu"), weights_only=True)
+
+        keyname = "params_ema" if "params_ema" in loadnet else "params"
+        state = loadnet[keyname]
+        self._adapt_declared_scale(model, state)
+        model.load_state_dict(state, strict=True)
+        model.eval()
+        self.model = model.to(self.device)
+        if self.half:
+            self.model = self.model.half()
+
+    @staticmethod
+    def _adapt_declared_scale(model, state):
+        """The reference declares RRDBNet(num_in_ch=3, ...) without scale=2 and then loads
+        RealESRGAN_x2plus weights, whose conv_first has 12 input channels
+        (standalone/direct_esrgan.py:104, standalone/download-x3-model.py:2-4 documents the
+        resulting 'channel mismatch').  A genuine x2plus checkpoint is recognised by
+        conv_first.weight having 4x the declared input channels and the model is switched to
+        upstream's scale=2 form (pixel_unshuffle + 12-channel conv_first) instead of failing."""
+        if not isinstance(model, RRDBNet) or "conv_first.weight" not in state:
+            return
+        cin = state["conv_first.weight"].shape[1]
+        if model.scale == 4 and cin == model.num_in_ch * 4:
+            warnings.warn("RRDBNet was declared without scale=2 but the checkpoint's conv_first takes "
+                          f"{cin} channels: treating it as the scale=2 (pixel_unshuffle) network")
+            model.set_scale(2)
+        elif model.scale == 4 and cin == model.num_in_ch * 16:
+            model.set_scale(1)
+
+    def dni(self, net_a, net_b, dni_weight, key="params", loc="cpu"):
+        """Deep network interpolation: weighted sum of two checkpoints' tensors."""
+        if not isinstance(net_a, dict):
+            net_a = torch.load(net_a, map_location=torch.device(loc), weights_only=True)
+        if not isinstance(net_b, dict):
+            net_b = torch.load(net_b, map_location=torch.device(loc), weights_only=True)
+        for k, v_a in net_a[key].items():
+            net_a[key][k] = dni_weight[0] * v_a + dni_weight[1] * net_b[key][k]
+        return net_a
+
+    # ------------------------------------------------------------------ pre / process / post
+    def pre_process(self, img):
+        """HWC float32 RGB [0,1] -> self.img [1,3,H,W] on device; reflect pre-pad; pad to mod_scale."""
+        img = torch.from_numpy(np.transpose(img, (2, 0, 1))).float()
+        self.img = img.unsqueeze(0).to(self.device)
+        if self.half:
+            self.img = self.img.half()
+        if self.pre_pad != 0:
+            self.img = F.pad(self.img, (0, self.pre_pad, 0, self.pre_pad), "reflect")
+        if self.scale == 2:
+            self.mod_scale = 2
+        elif self.scale == 1:
+            self.mod_scale = 4
+        if self.mod_scale is not None:
+            self.mod_pad_h, self.mod_pad_w = 0, 0
+            _, _, h, w = self.img.size()
+            if h % self.mod_scale != 0:
+                self.mod_pad_h = self.mod_scale - h % self.mod_scale
+            if w % self.mod_scale != 0:
+                self.mod_pad_w = self.mod_scale - w % self.mod_scale
+            self.img = F.pad(self.img, (0, self.mod_pad_w, 0, self.mod_pad_h), "reflect")
+
+    def process(self):
+        self.output = self.model(self.img)
+
+    def tile_grid(self, height, width):
+        """The tile windows upstream's tile_process visits, in its order.  Each entry:
+        (padded input window y0,y1,x0,x1 ; output window y0,y1,x0,x1 ; crop inside the tile's output y0,y1,x0,x1)."""
+        tiles_x = math.ceil(width / self.tile_size)
+        tiles_y = math.ceil(height / self.tile_size)
+        s = self.scale
+        grid = []
+        for y in range(tiles_y):
+            for x in range(tiles_x):
+                ix0, iy0 = x * self.tile_size, y * self.tile_size
+                ix1, iy1 = min(ix0 + self.tile_size, width), min(iy0 + self.tile_size, height)
+                px0, px1 = max(ix0 - self.tile_pad, 0), min(ix1 + self.tile_pad, width)
+                py0, py1 = max(iy0 - self.tile_pad, 0), min(iy1 + self.tile_pad, height)
+                tw, th = ix1 - ix0, iy1 - iy0
+                cx0, cy0 = (ix0 - px0) * s, (iy0 - py0) * s
+                grid.append(((py0, py1, px0, px1), (iy0 * s, iy1 * s, ix0 * s, ix1 * s), (cy0, cy0 + th * s, cx0, cx0 + tw * s)))
+        return grid
+
+    def tile_process(self):
+        """Runs the network on overlapping tiles and pastes the un-padded centres (upstream
+        semantics, tile for tile).  Equal-shaped tiles are evaluated ``tile_batch`` at a time in one
+        forward call: batch elements are independent, so the values equal the serial loop's."""
+        batch, channel, height, width = self.img.shape
+        s = self.scale
+        self.output = self.img.new_zeros((batch, channel, height * s, width * s))
+        grid = self.tile_grid(height, width)
+        groups = {}
+        for t in grid:
+            (py0, py1, px0, px1) = t[0]
+            groups.setdefault((py1 - py0, px1 - px0), []).append(t)
+        nb = max(1, int(self.tile_batch)) if batch == 1 else 1
+        for tiles in groups.values():
+            for i in range(0, len(tiles), nb):
+                chunk = tiles[i:i + nb]
+                if len(chunk) == 1:
+                    (py0, py1, px0, px1) = chunk[0][0]
+                    inp = self.img[:, :, py0:py1, px0:px1]
+                else:
+                    inp = torch.cat([self.img[:, :, t[0][0]:t[0][1], t[0][2]:t[0][3]] for t in chunk], 0)
+                with torch.no_grad():
+                    out = self.model(inp)
+                for j, (_, (oy0, oy1, ox0, ox1), (cy0, cy1, cx0, cx1)) in enumerate(chunk):
+                    o = out[j:j + 1] if len(chunk) > 1 else out
+                    self.output[:, :, oy0:oy1, ox0:ox1] = o[:, :, cy0:cy1, cx0:cx1]
+
+    def post_process(self):
+        if self.mod_scale is not None:
+            _, _, h, w = self.output.size()
+            self.output = self.output[:, :, 0:h - self.mod_pad_h * self.scale, 0:w - self.mod_pad_w * self.scale]
+        if self.pre_pad != 0:
+            _, _, h, w = self.output.size()
+            self.output = self.output[:, :, 0:h - self.pre_pad * self.scale, 0:w - self.pre_pad * self.scale]
+        return self.output
+
+    def _run(self):
+        if self.tile_size > 0:
+            self.tile_process()
+        else:
+            self.process()
+        return self.post_process()
+
+    # ------------------------------------------------------------------ enhance
+    def _fused_u8_ok(self, img):
+        """The fused u8 kernel path applies when the call reduces to one network evaluation of a
+        plain 8-bit BGR frame: no tiling needed, no pre_pad / mod_pad, HIP-backed model."""
+        if not isinstance(self.model, RRDBNet) or self.device.type != "cuda":
+            return False
+        if img.dtype != np.uint8 or img.ndim != 3 or img.shape[2] != 3 or self.pre_pad != 0:
+            return False
+        h, w = img.shape[:2]
+        if self.tile_size > 0 and (h > self.tile_size or w > self.tile_size):
+            return False
+        ms = {2: 2, 1: 4}.get(self.scale, 1)
+        if h % ms or w % ms:
+            return False
+        return self.model.num_in_ch == 3 and self.model.num_out_ch == 3 and self.model.out_scale() == self.scale
+
+    @torch.no_grad()
+    def enhance_float(self, img):
+        """Everything of enhance() up to (not including) quantisation: returns (HWC float32 in
+        [0,1] in BGR(A)/gray order, img_mode, max_range)."""
+        img = img.astype(np.float32)
+        if np.max(img) > 256:  # 16-bit image
+            max_range = 65535
+        else:
+            max_range = 255
+        img = img / max_range
+        if len(img.shape) == 2:  # gray image
+            img_mode = "L"
+            img = _gray2rgb(img)
+        elif img.shape[2] == 4:  # RGBA image with alpha channel
+            img_mode = "RGBA"
+            alpha = img[:, :, 3]
+            img = img[:, :, 0:3][:, :, ::-1]
+            alpha = _gray2rgb(alpha)
+        else:
+            img_mode = "RGB"
+            img = img[:, :, ::-1]
+
+        self.pre_process(np.ascontiguousarray(img))
+        output_img = self._run()
+        output_img = output_img.data.squeeze().float().cpu().clamp_(0, 1).numpy()
+        output_img = np.transpose(output_img[[2, 1, 0], :, :], (1, 2, 0))
+        if img_mode == "L":
+            output_img = _bgr2gray(output_img)
+
+        if img_mode == "RGBA":
+            self.pre_process(np.ascontiguousarray(alpha))
+            output_alpha = self._run()
+            output_alpha = output_alpha.data.squeeze().float().cpu().clamp_(0, 1).numpy()
+            output_alpha = np.transpose(output_alpha[[2, 1, 0], :, :], (1, 2, 0))
+            output_alpha = _bgr2gray(output_alpha)
+            output_img = np.concatenate([output_img, output_alpha[:, :, None]], axis=2)
+        return output_img, img_mode, max_range
+
+    @torch.no_grad()
+    def enhance(self, img, outscale=None, alpha_upsampler="realesrgan"):
+        """img: HWC uint8/uint16 BGR | BGRA | gray ndarray -> (ndarray of the same kind, upscaled; img_mode)."""
+        h_input, w_input = img.shape[0:2]
+        if alpha_upsampler != "realesrgan" and img.ndim == 3 and img.shape[2] == 4:
+            raise NotImplementedError("alpha_upsampler other than 'realesrgan' needs cv2.resize, which is not bundled")
+
+        if self._fused_u8_ok(img):
+            # /255, BGR->RGB, network, clamp, RGB->BGR, x255, round -- all inside the HIP path
+            x = torch.from_numpy(np.ascontiguousarray(img)).to(self.device)
+            output = self.model.forward_u8(x, flip_rgb=True, round_nearest=True).cpu().numpy()
+            img_mode = "RGB"
+        else:
+            output_img, img_mode, max_range = self.enhance_float(img)
+            if max_range == 65535:  # 16-bit image
+                output = (output_img * 65535.0).round().astype(np.uint16)
+            else:
+                output = (output_img * 255.0).round().astype(np.uint8)
+
+        if outscale is not None and outscale != float(self.scale):
+            try:
+                import cv2
+            except ImportError as e:  # pragma: no cover
+                raise NotImplementedError("outscale != scale needs cv2.resize(INTER_LANCZOS4); cv2 is not installed") from e
+            output = cv2.resize(output, (int(w_input * outscale), int(h_input * outscale)), interpolation=cv2.INTER_LANCZOS4)
+        return output, img_mode

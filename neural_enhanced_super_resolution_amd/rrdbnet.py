@@ -1,0 +1,277 @@
+"""``RRDBNet`` drop-in: same constructor, state_dict key names and call signature as
+``basicsr.archs.rrdbnet_arch.RRDBNet`` (basicsr>=1.4.2, requirements.txt:10), which the
+reference builds at nesr/nesr.py:216, standalone/direct_esrgan.py:104 and
+standalone/superres_project.py:69 and calls at nesr/nesr.py:891,935 (``model(img_12ch)``).
+
+The module owns ordinary torch Parameters under upstream's names (so ``load_state_dict(strict=True)``,
+``.parameters()``, ``.to()``, ``.eval()`` behave as the reference expects, nesr/nesr.py:888,962-973),
+but its ``forward`` is the hand-written HIP path in libnesr_hip.so, reached through the C ABI.
+There is no torch/CPU implementation of forward here: a non-CUDA input raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from . import _lib
+
+
+def conv_first_in_ch(num_in_ch: int, scale: int) -> int:
+    """basicsr RRDBNet.__init__: scale 2 -> x4 channels (pixel_unshuffle 2), scale 1 -> x16."""
+    return num_in_ch * {2: 4, 1: 16}.get(scale, 1)
+
+
+def rrdbnet_state_dict_spec(num_in_ch=3, num_out_ch=3, scale=4, num_feat=64, num_block=23, num_grow_ch=32):
+    """Ordered {key: shape} of the 702 (for 23 blocks) tensors of an RRDBNet checkpoint."""
+    spec = OrderedDict()
+
+    def conv(name, cin, cout):
+        spec[name + ".weight"] = (cout, cin, 3, 3)
+        spec[name + ".bias"] = (cout,)
+
+    conv("conv_first", conv_first_in_ch(num_in_ch, scale), num_feat)
+    for b in range(num_block):
+        for r in (1, 2, 3):
+            for k in (1, 2, 3, 4):
+                conv(f"body.{b}.rdb{r}.conv{k}", num_feat + (k - 1) * num_grow_ch, num_grow_ch)
+            conv(f"body.{b}.rdb{r}.conv5", num_feat + 4 * num_grow_ch, num_feat)
+    for name in ("conv_body", "conv_up1", "conv_up2", "conv_hr"):
+        conv(name, num_feat, num_feat)
+    conv("conv_last", num_feat, num_out_ch)
+    return spec
+
+
+class _ConvParams(nn.Module):
+    """Parameter holder for one 3x3 conv (weight OIHW + bias).  Not callable: the arithmetic
+    happens in the HIP library, never in torch."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(cout, cin, 3, 3), requires_grad=False)
+        self.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("_ConvParams holds weights only; RRDBNet.forward runs in libnesr_hip.so")
+
+
+class _RDBParams(nn.Module):
+    def __init__(self, nf, gc):
+        super().__init__()
+        for k in range(1, 5):
+            setattr(self, f"conv{k}", _ConvParams(nf + (k - 1) * gc, gc))
+        self.conv5 = _ConvParams(nf + 4 * gc, nf)
+
+
+class _RRDBParams(nn.Module):
+    def __init__(self, nf, gc):
+        super().__init__()
+        self.rdb1 = _RDBParams(nf, gc)
+        self.rdb2 = _RDBParams(nf, gc)
+        self.rdb3 = _RDBParams(nf, gc)
+
+
+class RRDBNet(nn.Module):
+    """Networks consisting of Residual in Residual Dense Blocks (ESRGAN / Real-ESRGAN generator).
+
+    Args mirror upstream: num_in_ch, num_out_ch, scale=4, num_feat=64, num_block=23, num_grow_ch=32.
+    Extra keyword ``compute_dtype``: "f32" (default; the reference's half=False) or "bf16".
+    """
+
+    def __init__(self, num_in_ch, num_out_ch, scale=4, num_feat=64, num_block=23, num_grow_ch=32,
+                 compute_dtype="f32"):
+        super().__init__()
+        self.num_in_ch = num_in_ch
+        self.num_out_ch = num_out_ch
+        self.scale = scale
+        self.num_feat = num_feat
+        self.num_block = num_block
+        self.num_grow_ch = num_grow_ch
+        self.compute_dtype = compute_dtype
+        self._build_params()
+        self._ctx = None          # (ctypes handle, device index, dtype code)
+        self._dirty = True        # parameters changed since the last upload
+
+    # ------------------------------------------------------------------ parameters
+    def _build_params(self):
+        cin0 = conv_first_in_ch(self.num_in_ch, self.scale)
+        self.conv_first = _ConvParams(cin0, self.num_feat)
+        self.body = nn.Sequential(*[_RRDBParams(self.num_feat, self.num_grow_ch) for _ in range(self.num_block)])
+        self.conv_body = _ConvParams(self.num_feat, self.num_feat)
+        self.conv_up1 = _ConvParams(self.num_feat, self.num_feat)
+        self.conv_up2 = _ConvParams(self.num_feat, self.num_feat)
+        self.conv_hr = _ConvParams(self.num_feat, self.num_feat)
+        self.conv_last = _ConvParams(self.num_feat, self.num_out_ch)
+
+    def set_scale(self, scale):
+        """Re-declares the network for another upstream ``scale`` (changes conv_first's input
+        channels); used by RealESRGANer to accept genuine x2plus weights for a model that was
+        declared without ``scale=2`` (the reference does that: SURVEY.md Appendix A)."""
+        if scale == self.scale:
+            return
+        self.scale = scale
+        dev = self.conv_body.weight.device
+        self.conv_first = _ConvParams(conv_first_in_ch(self.num_in_ch, scale), self.num_feat).to(dev)
+        self._release()
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._dirty = True
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._dirty = True
+        p = self.conv_body.weight
+        if p.dtype in (torch.float16, torch.bfloat16):
+            self.compute_dtype = "bf16"   # .half(): upstream's fp16 switch selects the bf16 MFMA kernels here
+        return out
+
+    # ------------------------------------------------------------------ HIP context
+    def _release(self):
+        if self._ctx is not None:
+            _lib.load().nesr_destroy(self._ctx[0])
+            self._ctx = None
+        self._dirty = True
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _dtype_code(self):
+        if self.compute_dtype in ("f32", "fp32", torch.float32):
+            return _lib.DTYPE_F32
+        if self.compute_dtype in ("bf16", torch.bfloat16, "half", torch.float16):
+            return _lib.DTYPE_BF16
+        raise ValueError(f"compute_dtype {self.compute_dtype!r}: expected 'f32' or 'bf16'")
+
+    def _context(self, device: torch.device):
+        lib = _lib.load()
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        code = self._dtype_code()
+        if self._ctx is not None and (self._ctx[1] != index or self._ctx[2] != code):
+            self._release()
+        if self._ctx is None:
+            handle = ctypes.c_void_p()
+            unshuffle = {2: 2, 1: 4}.get(self.scale, 0)
+            _lib.check(lib.nesr_create(ctypes.byref(handle), index, conv_first_in_ch(self.num_in_ch, self.scale),
+                                       unshuffle, self.num_feat, self.num_block, self.num_grow_ch, self.num_out_ch, code),
+                       "nesr_create")
+            self._ctx = (handle, index, code)
+            self._dirty = True
+        if self._dirty:
+            handle = self._ctx[0]
+            for key, t in self.state_dict().items():
+                arr = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+                shape = (ctypes.c_int64 * arr.dim())(*arr.shape)
+                _lib.check(lib.nesr_load_weight(handle, key.encode(), ctypes.c_void_p(arr.data_ptr()), shape, arr.dim()),
+                           f"nesr_load_weight({key})")
+            _lib.check(lib.nesr_finalize_weights(handle), "nesr_finalize_weights")
+            self._dirty = False
+        return self._ctx[0]
+
+    # ------------------------------------------------------------------ forward
+    def out_scale(self):
+        """Output size / input size of forward(): 4 / unshuffle factor."""
+        return {2: 2, 1: 1}.get(self.scale, 4)
+
+    def _require_cuda(self, x):
+        if x.device.type != "cuda":
+            raise RuntimeError(
+                "RRDBNet.forward runs only on an AMD GPU through libnesr_hip.so; got a tensor on "
+                f"{x.device}. There is no CPU/PyTorch fallback for this path.")
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x: [N, num_in_ch, H, W] float on a ROCm device -> [N, num_out_ch, H*s, W*s]."""
+        self._require_cuda(x)
+        if x.dim() != 4:
+            raise ValueError(f"expected NCHW input, got shape {tuple(x.shape)}")
+        in_dtype = x.dtype
+        xf = x.to(torch.float32).contiguous()
+        n, c, h, w = xf.shape
+        u = {2: 2, 1: 4}.get(self.scale, 1)
+        if h % u or w % u:
+            raise AssertionError(f"hh({h}) and hw({w}) must be divisible by {u}")  # upstream pixel_unshuffle asserts
+        s = self.out_scale()
+        with torch.cuda.device(xf.device):
+            ctx = self._context(xf.device)
+            y = torch.empty((n, self.num_out_ch, h * s, w * s), dtype=torch.float32, device=xf.device)
+            stream = torch.cuda.current_stream(xf.device).cuda_stream
+            _lib.check(_lib.load().nesr_forward(ctx, ctypes.c_void_p(xf.data_ptr()), n, c, h, w,
+                                                ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(stream)), "nesr_forward")
+        return y if in_dtype == torch.float32 else y.to(in_dtype)
+
+    @torch.no_grad()
+    def forward_u8(self, img_hwc_u8, flip_rgb=True, round_nearest=True):
+        """Fused image path: u8 HWC [H,W,3] device tensor -> u8 HWC [H*s,W*s,3].
+
+        flip_rgb/round_nearest = (True, True) reproduces RealESRGANer.enhance's /255, BGR<->RGB,
+        clamp, x255, round; (False, False) reproduces nesr/nesr.py:851-857,894-898 (truncation)."""
+        self._require_cuda(img_hwc_u8)
+        if img_hwc_u8.dtype != torch.uint8 or img_hwc_u8.dim() != 3 or img_hwc_u8.shape[2] != 3:
+            raise ValueError("expected a uint8 [H, W, 3] tensor")
+        x = img_hwc_u8.contiguous()
+        h, w, _ = x.shape
+        s = self.out_scale()
+        with torch.cuda.device(x.device):
+            ctx = self._context(x.device)
+            y = torch.empty((h * s, w * s, 3), dtype=torch.uint8, device=x.device)
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            _lib.check(_lib.load().nesr_forward_u8(ctx, ctypes.c_void_p(x.data_ptr()), h, w, ctypes.c_void_p(y.data_ptr()),
+                                                   1 if flip_rgb else 0,
+                                                   _lib.ROUND_NEAREST if round_nearest else _lib.ROUND_TRUNC,
+                                                   ctypes.c_void_p(stream)), "nesr_forward_u8")
+        return y
+
+    # ------------------------------------------------------------------ measurement helpers
+    def forward_flops(self, n, h, w):
+        """Algorithmic FLOPs of one forward on [n, *, h, w]."""
+        macs = 0
+        u = {2: 2, 1: 4}.get(self.scale, 1)
+        px = n * (h // u) * (w // u)
+        nf, gc = self.num_feat, self.num_grow_ch
+        rdb = sum(9 * (nf + k * gc) * gc for k in range(4)) + 9 * (nf + 4 * gc) * nf
+        macs += 9 * conv_first_in_ch(self.num_in_ch, self.scale) * nf + self.num_block * 3 * rdb + 9 * nf * nf
+        macs += 4 * 9 * nf * nf + 16 * 9 * nf * nf * 2 + 16 * 9 * nf * self.num_out_ch
+        return 2.0 * macs * px
+
+    def set_kernel_timing(self, device, enable=True):
+        ctx = self._context(torch.device(device))
+        _lib.check(_lib.load().nesr_set_kernel_timing(ctx, 1 if enable else 0), "nesr_set_kernel_timing")
+
+    def kernel_time(self):
+        """(total ms, launches, algorithmic flops) of the dense-block convs since the last call."""
+        if self._ctx is None:
+            return 0.0, 0, 0.0
+        ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+        _lib.check(_lib.load().nesr_kernel_time_ms(self._ctx[0], ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)),
+                   "nesr_kernel_time_ms")
+        return ms.value, n.value, fl.value
+
+
+def conv3x3(x, weight, bias, lrelu=False, upsample=False, dtype="f32"):
+    """Single fused layer through the C ABI (test hook): conv3x3(pad 1) + bias [+ LeakyReLU(0.2)],
+    optionally on the nearest-x2 upsample of x.  x NCHW float32 on a ROCm device."""
+    if x.device.type != "cuda":
+        raise RuntimeError("conv3x3 runs only on an AMD GPU through libnesr_hip.so (no CPU fallback)")
+    lib = _lib.load()
+    x = x.to(torch.float32).contiguous()
+    n, cin, h, w = x.shape
+    wt = weight.detach().to("cpu", torch.float32).contiguous()
+    bs = bias.detach().to("cpu", torch.float32).contiguous()
+    cout = wt.shape[0]
+    up = 1 if upsample else 0
+    y = torch.empty((n, cout, h << up, w << up), dtype=torch.float32, device=x.device)
+    index = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _lib.check(lib.nesr_conv3x3(index, _lib.DTYPE_BF16 if dtype == "bf16" else _lib.DTYPE_F32,
+                                    ctypes.c_void_p(x.data_ptr()), n, cin, h, w, ctypes.c_void_p(wt.data_ptr()),
+                                    ctypes.c_void_p(bs.data_ptr()), cout, 1 if lrelu else 0, up,
+                                    ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(stream)), "nesr_conv3x3")
+    return y

@@ -1,0 +1,79 @@
+"""Per-layer parity of the HIP 3x3 conv (through the C ABI entry nesr_conv3x3) against torch CPU
+ops -- the primitives the oracle is made of.  Shapes: every (Cin, Cout) RRDBNet uses
+(SURVEY.md section 8(c) golden item 1)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(3, 64), (12, 64), (64, 32), (96, 32), (128, 32), (160, 32), (192, 64), (64, 64), (64, 3)]
+F32_TOL = 2e-5   # f32 MFMA is a k-ordered fmaf chain; oneDNN sums in another order
+
+
+def _case(cin, cout, h, w, seed, n=1):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wgt = torch.randn(cout, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    return x, wgt, b
+
+
+@pytest.mark.parametrize("cin,cout", SHAPES)
+@pytest.mark.parametrize("lrelu", [False, True])
+def test_conv3x3_f32_matches_torch(cuda_device, cin, cout, lrelu):
+    from neural_enhanced_super_resolution_amd import conv3x3
+    x, w, b = _case(cin, cout, 24, 40, seed=cin * 100 + cout)
+    ref = F.conv2d(x, w, b, padding=1)
+    if lrelu:
+        ref = F.leaky_relu(ref, 0.2)
+    got = conv3x3(x.to(cuda_device), w, b, lrelu=lrelu).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < F32_TOL * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (7, 5), (8, 16), (9, 17), (33, 47), (16, 130)])
+def test_conv3x3_f32_ragged_sizes(cuda_device, h, w):
+    from neural_enhanced_super_resolution_amd import conv3x3
+    x, wgt, b = _case(64, 32, h, w, seed=h * 1000 + w, n=2)
+    ref = F.conv2d(x, wgt, b, padding=1)
+    got = conv3x3(x.to(cuda_device), wgt, b).cpu()
+    assert (got - ref).abs().max().item() < F32_TOL * max(1.0, ref.abs().max().item())
+
+
+def test_conv3x3_f32_upsample_fused(cuda_device):
+    from neural_enhanced_super_resolution_amd import conv3x3
+    x, wgt, b = _case(64, 64, 13, 21, seed=5)
+    ref = F.leaky_relu(F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wgt, b, padding=1), 0.2)
+    got = conv3x3(x.to(cuda_device), wgt, b, lrelu=True, upsample=True).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < F32_TOL * max(1.0, ref.abs().max().item())
+
+
+def test_conv3x3_asymmetric_taps(cuda_device):
+    """One-hot weights: catches swapped dy/dx, transposed C/D maps and channel permutations exactly."""
+    from neural_enhanced_super_resolution_amd import conv3x3
+    cin, cout = 16, 32
+    x = torch.arange(cin * 6 * 7, dtype=torch.float32).reshape(1, cin, 6, 7) % 251
+    for tap in range(9):
+        w = torch.zeros(cout, cin, 3, 3)
+        for o in range(cout):
+            w[o, (o * 5 + tap) % cin, tap // 3, tap % 3] = 1.0
+        b = torch.arange(cout, dtype=torch.float32)
+        ref = F.conv2d(x, w, b, padding=1)
+        got = conv3x3(x.to(cuda_device), w, b).cpu()
+        assert torch.equal(got, ref), f"tap {tap}"
+
+
+@pytest.mark.parametrize("cin,cout", [(12, 64), (64, 32), (160, 32), (192, 64), (64, 3)])
+def test_conv3x3_bf16_matches_bf16_rounded_reference(cuda_device, cin, cout):
+    """bf16 kernel: operands are bf16-rounded, accumulation is f32 -> compare against the torch
+    conv of the bf16-rounded operands (tolerance = output bf16 rounding + summation order)."""
+    from neural_enhanced_super_resolution_amd import conv3x3
+    x, w, b = _case(cin, cout, 24, 40, seed=cin + cout)
+    xr, wr = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv2d(xr, wr, b, padding=1)
+    got = conv3x3(x.to(cuda_device), w, b, dtype="bf16").cpu()
+    scale = max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() < 2 ** -7 * scale   # output stored as bf16 (8 bits of mantissa)
