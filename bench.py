@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline bench: output megapixels/s of RealESRGAN_x2plus x2 upscaling on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1 directly; N>1 under torch.distributed.run)
+
+Workload (BASELINE.json configs[1], "c2"): synthetic 512x512 -> 1024x1024 RealESRGAN_x2plus, fp32,
+single tile, one frame per step per GPU, input already resident in HBM as the NCHW float tensor
+RealESRGANer.process() hands to ``self.model`` (the drop-in boundary).  Frames (= tiles
+of the reference's tile grid) are independent units, so N GPUs run N frames per step with no
+data-path collective ("scaling": "weak").  Other workloads: --workload c3 (2160p, bf16, reference
+tile grid 512/10) and c4 (1080p x4plus).
+
+One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel family (the 345
+dense-block 3x3 convs = 92 % of the FLOPs): algorithmic FLOPs / HIP-event time on the launch
+stream, against the dense MFMA peak of the dtype.  `cpu_baseline` is the torch-CPU oracle
+(oracle/, a restatement: the reference's own RRDBNet lives in the absent basicsr package) timed on
+this host's cores on a bounded crop of the same frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md, chip-level table)
+
+WORKLOADS = {
+    # name: (H, W, num_in_ch, upstream scale, netscale, dtype, tile, tile_pad)
+    "c2": dict(h=512, w=512, scale=2, dtype="f32", tile=0, tile_pad=10, desc="512x512->1024x1024 RealESRGAN_x2plus fp32 single tile"),
+    "c2-bf16": dict(h=512, w=512, scale=2, dtype="bf16", tile=0, tile_pad=10, desc="512x512->1024x1024 RealESRGAN_x2plus bf16 single tile"),
+    "c3": dict(h=2160, w=3840, scale=2, dtype="bf16", tile=512, tile_pad=10, desc="3840x2160->7680x4320 RealESRGAN_x2plus bf16, tile 512/10"),
+    "c3-f32": dict(h=2160, w=3840, scale=2, dtype="f32", tile=512, tile_pad=10, desc="3840x2160->7680x4320 RealESRGAN_x2plus fp32, tile 512/10"),
+    "c4": dict(h=1080, w=1920, scale=4, dtype="bf16", tile=512, tile_pad=10, desc="1920x1080->7680x4320 RealESRGAN_x4plus bf16, tile 512/10"),
+}
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads(cap=16):
+    """Threads for the CPU baseline: affinity mask, capped by the cgroup CPU quota and by `cap`
+    (the GPU box gives one GPU's job a 16-CPU share; more threads than that only thrash)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(sd, frame, scale, crop, threads):
+    """Times the oracle on a crop of the frame; returns (dict, oracle float output of the crop)."""
+    import numpy as np
+    import torch
+    from oracle.rrdbnet_ref import RRDBNetRef
+    torch.set_num_threads(threads)
+    ref = RRDBNetRef(3, 3, scale=scale)
+    ref.load_state_dict(sd, strict=True)
+    x = torch.from_numpy(np.ascontiguousarray(frame[:crop, :crop, ::-1].transpose(2, 0, 1))).float().div(255.0).unsqueeze(0)
+    with torch.no_grad():
+        ref(x[:, :, :32, :32])           # warm the thread pool / oneDNN primitives
+        t0 = time.perf_counter()
+        y = ref(x)
+        dt = time.perf_counter() - t0
+    netscale = {2: 2, 1: 1}.get(scale, 4)
+    mp = (crop * netscale) ** 2 / 1e6
+    return dict(value=round(mp / dt, 5), unit="MP/s", cores=threads, kind="port",
+                sample=f"{crop}x{crop} crop of the bench frame, one RRDBNet forward, {dt:.1f} s on {threads} torch threads"), x, y
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-crop", type=int, default=512, help="side of the crop the CPU oracle is timed on (0 = skip)")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from neural_enhanced_super_resolution_amd import RRDBNet, RealESRGANer
+    from neural_enhanced_super_resolution_amd.synth import synthetic_frame, synthetic_state_dict
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    assert torch.cuda.is_available(), "bench.py needs a ROCm GPU"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)   # RCCL
+
+    wl = WORKLOADS[args.workload]
+    scale, dtype = wl["scale"], wl["dtype"]
+    netscale = {2: 2, 1: 1}.get(scale, 4)
+    sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=scale)
+    frame = synthetic_frame(wl["h"], wl["w"], seed=rank)            # uint8 HWC BGR, one per rank
+    net = RRDBNet(3, 3, scale=scale, compute_dtype=dtype)
+    up = RealESRGANer(scale=netscale, model_path={"params_ema": sd}, model=net, tile=wl["tile"], tile_pad=wl["tile_pad"],
+                      pre_pad=0, half=False, device=dev)
+    model = up.model
+
+    # the boundary tensor: what enhance() -> pre_process() puts on the device
+    up.pre_process(np.ascontiguousarray(frame[:, :, ::-1].astype(np.float32) / 255.0))
+    x = up.img
+
+    def step():
+        if wl["tile"] > 0:
+            up.tile_process()
+            return up.output
+        return model(x)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    log(f"workload {args.workload} rank {rank}/{world}: model ready, warming up")
+    for _ in range(args.warmup):
+        y = step()
+    torch.cuda.synchronize(dev)
+    log("warmup done")
+    model.set_kernel_timing(dev, True)
+    model.kernel_time()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_launches, k_flops = model.kernel_time()
+    model.set_kernel_timing(dev, False)
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out_mp = wl["h"] * netscale * wl["w"] * netscale / 1e6
+    value = world * args.steps * out_mp / elapsed
+    frame_flops = net.forward_flops(1, wl["h"], wl["w"])
+
+    result = {
+        "metric": "output megapixels/sec, RealESRGAN_x2plus x2 upscale" if scale == 2 else "output megapixels/sec, RealESRGAN_x4plus x4 upscale",
+        "value": round(value, 3), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": dtype, "data": "synthetic (seeded frames, seeded random-init weights)",
+        "config": {"workload": f"{args.workload}: {wl['desc']}", "frames_per_step_per_gpu": 1,
+                   "boundary": "RRDBNet.forward on the device-resident NCHW f32 tensor of RealESRGANer.pre_process",
+                   "tflop_per_frame": round(frame_flops / 1e12, 4)},
+        "frames_per_s": round(world * args.steps / elapsed, 4),
+        "tflops_whole_net": round(world * args.steps * frame_flops / elapsed / 1e12, 2),
+    }
+    if k_ms > 0:
+        achieved = k_flops / (k_ms * 1e-3) / 1e12
+        peak = PEAK_TFLOPS[dtype]
+        result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                              "frac": round(achieved / peak, 4), "traffic": None,
+                              "kernel": "conv3x3_mfma_kernel (345 dense-block convs per frame)",
+                              "avg_launch_us": round(1e3 * k_ms / max(k_launches, 1), 2), "launches": int(k_launches)}
+
+    if rank == 0:
+        # host-to-host enhance() (PCIe + quantisation inclusive), reported beside the metric, never as `value`
+        log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
+        t1 = time.perf_counter()
+        out_u8, _ = up.enhance(frame)
+        torch.cuda.synchronize(dev)
+        result["enhance_host_to_host_mp_s"] = round(out_mp / (time.perf_counter() - t1), 3)
+        if args.cpu_crop > 0 and not args.no_parity:
+            crop = min(args.cpu_crop, wl["h"], wl["w"])
+            crop -= crop % 2
+            threads = host_threads()
+            log(f"cpu baseline: oracle on a {crop}x{crop} crop with {threads} threads")
+            base, xc, yref = cpu_baseline(sd, frame, scale, crop, threads)
+            log("cpu baseline done")
+            result["cpu_baseline"] = base
+            ygpu = model(xc.to(dev)).float().cpu()
+            err = (ygpu - yref).abs().max().item()
+            mse = ((ygpu - yref) ** 2).mean().item()
+            result["parity_vs_cpu_oracle"] = {"max_abs": float(f"{err:.3e}"), "psnr_db": round(10 * np.log10(1.0 / max(mse, 1e-30)), 2),
+                                             "sample": base["sample"].split(",")[0], "tolerance": 1e-3 if dtype == "f32" else None}
+            result["gpu_over_cpu"] = round(value / world / base["value"], 1)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
