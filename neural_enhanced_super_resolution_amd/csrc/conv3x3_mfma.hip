@@ -11,12 +11,14 @@
 //   wave      : one 32-pixel M-tile (2 rows x 16 cols) x NT 32-wide N-tiles
 //   K loop    : chunks of 32 bytes of input channels (8 f32 / 16 bf16); per chunk the
 //               (8+2)x(16+2) input halo tile and the 9 x chunk x N weight slab are staged
-//               global -> registers -> LDS, double-buffered, one barrier per chunk.
-//   A operand : lane (m = lane&31, h = lane>>5) reads the 16 bytes [16h, 16h+16) of its pixel's
-//               chunk with one ds_read_b128: f32 -> 4 channels, MFMA k-step j pairs channels
-//               {j, 4+j}; bf16 -> 8 channels = exactly the 32x32x16 A fragment (k = 8h + j).
-//   B operand : weights pre-packed on the host as [chunk][tap][h][n][16 B] so the matching
-//               ds_read_b128 is lane-contiguous (conflict-free).
+//               global -> registers -> LDS into a 3-slot ring (two chunks ahead), one barrier per
+//               chunk, first tap of the next chunk read before the barrier.
+//   pixels    : (the MFMA's B operand) lane (m = lane&31, h = lane>>5) reads the 16 bytes
+//               [16h, 16h+16) of its pixel's chunk with one ds_read_b128: f32 -> 4 channels, MFMA
+//               k-step j pairs channels {j, 4+j}; bf16 -> 8 channels = exactly the 32x32x16
+//               fragment (k = 8h + j).
+//   weights   : (the MFMA's A operand) pre-packed on the host as [chunk][tap][h][n][16 B] so the
+//               matching ds_read_b128 is lane-contiguous (conflict-free).
 //   LDS image : activations [h][pixel][16 B] (two planes), so 16 consecutive pixels are 256
 //               contiguous bytes.
 //   epilogue  : bias, LeakyReLU(0.2), up to two scaled residuals (RDB: x5*0.2+x; RRDB: out*0.2+x),
@@ -44,17 +46,22 @@ template <>
 struct Elem<false> {
     typedef float T;
     static constexpr int KG = 8;  // channels per 32-byte chunk
-    __device__ static float ld(const T* p) { return *p; }
-    __device__ static void st(T* p, float v) { *p = v; }
+    __device__ static f32x4 ld4(const T* p) { return *reinterpret_cast<const f32x4*>(p); }
+    __device__ static void st4(T* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 };
 template <>
 struct Elem<true> {
     typedef uint16_t T;
     static constexpr int KG = 16;
-    __device__ static float ld(const T* p) { return __uint_as_float(((unsigned)*p) << 16); }
-    __device__ static void st(T* p, float v) {
-        __bf16 b = (__bf16)v;  // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN preserving
-        *p = *reinterpret_cast<uint16_t*>(&b);
+    __device__ static f32x4 ld4(const T* p) {   // 4 bf16 (8 bytes) -> 4 f32
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u)};
+    }
+    __device__ static void st4(T* p, f32x4 v) {   // plain casts -> v_cvt_pk_bf16_f32 (RNE, NaN preserving)
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        const bf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, b);
     }
 };
 
@@ -66,7 +73,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
     constexpr int IN_F4 = 2 * NPIX;
     constexpr int W_F4 = 9 * 2 * 32 * NT;
     constexpr int STAGE_F4 = IN_F4 + W_F4;
-    constexpr int WL = (W_F4 + 255) / 256;
     f32x4* lds = reinterpret_cast<f32x4*>(smem);
 
     const int tid = threadIdx.x;
@@ -80,49 +86,56 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
     const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;
 
-    // ---- staging assignment, fixed across chunks
-    const T* in = static_cast<const T*>(a.in);
-    const T* isrc[2];
-    bool ivalid[2];
+    // ---- staging assignment, fixed across chunks and branch-free.  One chunk's LDS image is
+    // [input: 2 planes x 180 pixels | weights: 9 taps x 2 halves x 32*NT] 16-byte items; item k of
+    // round i (k = tid + 256 i, clamped to the last item: duplicates write identical bytes) has a
+    // per-thread source pointer that advances by a per-thread stride per chunk.  Out-of-image
+    // pixels (the conv's zero padding) load a valid dummy address and are zeroed by a select.
+    constexpr int TOTAL_F4 = STAGE_F4;
+    constexpr int R = (TOTAL_F4 + 255) / 256;
+    const char* src[R];
+    int cstride[R];
+    int slot[R];
+    bool zero[R];
+    {
+        const char* in = static_cast<const char*>(a.in);
+        const char* wsrc = static_cast<const char*>(a.w);
+        constexpr int ES = (int)sizeof(T);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int e = tid + 256 * i;
-        const int half = e >= NPIX ? 1 : 0;
-        const int p = e - half * NPIX;
-        const int py = p / PW, px = p - py * PW;
-        const int Y = y0 - 1 + py, X = x0 - 1 + px;
-        ivalid[i] = (e < IN_F4) && Y >= 0 && Y < a.h && X >= 0 && X < a.w_;
-        const int sy = ivalid[i] ? (Y >> a.up) : 0, sx = ivalid[i] ? (X >> a.up) : 0;
-        isrc[i] = in + (((size_t)n * a.in_h + sy) * a.in_w + sx) * a.in_stride + half * (KG / 2);
+        for (int i = 0; i < R; ++i) {
+            int k = tid + 256 * i;
+            k = k < TOTAL_F4 ? k : TOTAL_F4 - 1;
+            slot[i] = k;
+            if (k < IN_F4) {
+                const int half = k >= NPIX ? 1 : 0;
+                const int p = k - half * NPIX;
+                const int py = p / PW, px = p - py * PW;
+                const int Y = y0 - 1 + py, X = x0 - 1 + px;
+                const bool ok = Y >= 0 && Y < a.h && X >= 0 && X < a.w_;
+                const int sy = ok ? (Y >> a.up) : 0, sx = ok ? (X >> a.up) : 0;
+                src[i] = in + ((((size_t)n * a.in_h + sy) * a.in_w + sx) * a.in_stride) * ES + half * 16;
+                cstride[i] = 32;
+                zero[i] = !ok;
+            } else {
+                src[i] = wsrc + (size_t)(k - IN_F4) * 16;
+                cstride[i] = W_F4 * 16;
+                zero[i] = false;
+            }
+        }
     }
-    const f32x4* wsrc = static_cast<const f32x4*>(a.w);
 
-    f32x4 pin[2], pw[WL];
+    f32x4 pv[R];
     auto load_chunk = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            pin[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (ivalid[i]) pin[i] = *reinterpret_cast<const f32x4*>(isrc[i] + c * KG);
-        }
-        const f32x4* ws = wsrc + (size_t)c * W_F4;
-#pragma unroll
-        for (int i = 0; i < WL; ++i) {
-            const int k = tid + 256 * i;
-            if (k < W_F4) pw[i] = ws[k];
+        for (int i = 0; i < R; ++i) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src[i] + (size_t)c * cstride[i]);
+            pv[i] = zero[i] ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
         }
     };
     auto store_chunk = [&](int stage) {
         f32x4* st = lds + stage * STAGE_F4;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e = tid + 256 * i;
-            if (e < IN_F4) st[e] = pin[i];
-        }
-#pragma unroll
-        for (int i = 0; i < WL; ++i) {
-            const int k = tid + 256 * i;
-            if (k < W_F4) st[IN_F4 + k] = pw[i];
-        }
+        for (int i = 0; i < R; ++i) st[slot[i]] = pv[i];
     };
 
     // ---- per-lane compute coordinates
@@ -138,69 +151,164 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const int nchunks = a.cin / KG;
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const bool more = (c + 1) < nchunks;
-        if (more) load_chunk(c + 1);
-        const f32x4* st = lds + (c & 1) * STAGE_F4;
+    // operand registers: a 3-slot rotation, tap t lives in slot t % 3 and is read two taps ahead
+    f32x4 opa[3];
+    f32x4 opb[3][NT];
+    auto read_tap = [&](const f32x4* st, int tap, int sl) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        opa[sl] = st[a_base + dy * PW + dx];
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int dy = tap / 3, dx = tap - dy * 3;
-            const f32x4 av = st[a_base + dy * PW + dx];
-            f32x4 bv[NT];
+        for (int t = 0; t < NT; ++t) opb[sl][t] = st[b_base + tap * 2 * (32 * NT) + t * 32];
+    };
+    auto mfma_tap = [&](int sl) {
+        if constexpr (BF) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) bv[t] = st[b_base + tap * 2 * (32 * NT) + t * 32];
-            if constexpr (BF) {
+            for (int t = 0; t < NT; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, opb[sl][t]),
+                                                                 __builtin_bit_cast(bf16x8, opa[sl]), acc[t], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av),
-                                                                     __builtin_bit_cast(bf16x8, bv[t]), acc[t], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[t][j], acc[t], 0, 0, 0);
-            }
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(opb[sl][t][j], opa[sl][j], acc[t], 0, 0, 0);
         }
-        if (more) store_chunk((c + 1) & 1);
+    };
+
+    // 3-slot LDS ring: chunk c+2 is staged while chunk c is computed, so chunk c+1 is already
+    // visible (previous iteration's barrier) and the rolling operand prefetch runs straight across
+    // the chunk boundary: taps 0,1 of chunk c+1 are read during taps 7,8 of chunk c, before the
+    // barrier.  sched_barrier pins "reads for tap+2, then MFMAs of tap": left alone, hipcc sinks the
+    // ds_reads to just before their s_waitcnt and the single-accumulator MFMA chain stalls on them.
+    load_chunk(0);
+    store_chunk(0);
+    load_chunk(nchunks > 1 ? 1 : 0);
+    store_chunk(1);
+    __syncthreads();
+    const f32x4* s_cur = lds;
+    const f32x4* s_nxt = lds + STAGE_F4;
+    int stage_fill = 2;
+    read_tap(s_cur, 0, 0);
+    read_tap(s_cur, 1, 1);
+    for (int c = 0; c < nchunks; ++c) {
+        load_chunk(c + 2 < nchunks ? c + 2 : nchunks - 1);   // clamped: a redundant reload is harmless
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 2 < 9)
+                read_tap(s_cur, tap + 2, (tap + 2) % 3);
+            else
+                read_tap(s_nxt, tap + 2 - 9, (tap + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_tap(tap % 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        store_chunk(stage_fill);
         __syncthreads();
+        s_cur = s_nxt;
+        s_nxt = lds + stage_fill * STAGE_F4;
+        stage_fill = stage_fill == 2 ? 0 : stage_fill + 1;
     }
 
-    // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31 (-> cout), row = (r&3)+8*(r>>2)+4*(lane>>5) (-> pixel)
-    T* out = static_cast<T*>(a.out);
-    T* out2 = static_cast<T*>(a.out2);
-    const T* res1 = static_cast<const T*>(a.res1);
-    const T* res2 = static_cast<const T*>(a.res2);
+    // ---- epilogue.  The weights are the MFMA's A operand and the pixels its B operand, so in the
+    // 32x32 C/D map col = lane&31 is this lane's pixel and rows (r&3)+8*(r>>2)+4*(lane>>5) are output
+    // channels: every lane owns 4 x NT runs of 4 consecutive channels of ONE pixel -> 16-byte
+    // residual loads and stores, all loads issued before any use (no per-element branches).
+    const int Y = y0 + prow, X = x0 + pcol;
+    const bool valid = Y < a.h && X < a.w_;
+    const size_t pix = ((size_t)n * a.h + (valid ? Y : 0)) * a.w_ + (valid ? X : 0);
+    f32x4 r1[NT][4], r2[NT][4], bs[NT][4];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int co = t * 32 + m;
-        const float bias = a.bias[co];
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int mm = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const int Y = y0 + 2 * wave + (mm >> 4), X = x0 + (mm & 15);
-            if (Y >= a.h || X >= a.w_) continue;
-            const size_t pix = ((size_t)n * a.h + Y) * a.w_ + X;
-            float v = acc[t][r] + bias;
-            if (a.lrelu) v = v > 0.f ? v : v * 0.2f;
-            if (res1) v = __fadd_rn(__fmul_rn(v, a.s1), Elem<BF>::ld(res1 + pix * a.res1_stride + co));
-            if (res2) v = __fadd_rn(__fmul_rn(v, a.s2), Elem<BF>::ld(res2 + pix * a.res2_stride + co));
-            if (out) Elem<BF>::st(out + pix * a.out_stride + a.out_coff + co, v);
-            if (out2) Elem<BF>::st(out2 + pix * a.out2_stride + co, v);
-            if (co < a.cout_real) {
-                if (a.out_nchw) a.out_nchw[(((size_t)n * a.cout_real + co) * a.h + Y) * a.w_ + X] = v;
+        for (int g = 0; g < 4; ++g) bs[t][g] = *reinterpret_cast<const f32x4*>(a.bias + t * 32 + 8 * g + 4 * hh);
+    if (a.res1) {
+        const T* rp = static_cast<const T*>(a.res1) + pix * a.res1_stride + 4 * hh;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) r1[t][g] = Elem<BF>::ld4(rp + t * 32 + 8 * g);
+    }
+    if (a.res2) {
+        const T* rp = static_cast<const T*>(a.res2) + pix * a.res2_stride + 4 * hh;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) r2[t][g] = Elem<BF>::ld4(rp + t * 32 + 8 * g);
+    }
+    f32x4 v[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float x = acc[t][4 * g + q] + bs[t][g][q];
+                if (a.lrelu) x = x > 0.f ? x : x * 0.2f;
+                v[t][g][q] = x;
+            }
+        }
+    if (a.res1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[t][g][q] = __fadd_rn(__fmul_rn(v[t][g][q], a.s1), r1[t][g][q]);
+    }
+    if (a.res2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[t][g][q] = __fadd_rn(__fmul_rn(v[t][g][q], a.s2), r2[t][g][q]);
+    }
+    if (valid) {
+        if (a.out) {
+            T* op = static_cast<T*>(a.out) + pix * a.out_stride + a.out_coff + 4 * hh;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) Elem<BF>::st4(op + t * 32 + 8 * g, v[t][g]);
+        }
+        if (a.out2) {
+            T* op = static_cast<T*>(a.out2) + pix * a.out2_stride + 4 * hh;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) Elem<BF>::st4(op + t * 32 + 8 * g, v[t][g]);
+        }
+        if (a.cout_real > 0 && hh == 0) {
+            // conv_last: channels 0..cout_real-1 (<= 4) live in v[0][0] of the lower half-wave
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (q >= a.cout_real) break;
+                const float x = v[0][0][q];
+                if (a.out_nchw) a.out_nchw[(((size_t)n * a.cout_real + q) * a.h + Y) * a.w_ + X] = x;
                 if (a.out_u8) {
-                    float q = fminf(fmaxf(v, 0.f), 1.f) * 255.0f;
-                    q = a.u8_round ? rintf(q) : truncf(q);
-                    const int ch = a.u8_flip ? (a.cout_real - 1 - co) : co;
-                    a.out_u8[pix * a.cout_real + ch] = (uint8_t)q;
+                    float qv = fminf(fmaxf(x, 0.f), 1.f) * 255.0f;
+                    qv = a.u8_round ? rintf(qv) : truncf(qv);
+                    const int ch = a.u8_flip ? (a.cout_real - 1 - q) : q;
+                    a.out_u8[pix * a.cout_real + ch] = (uint8_t)qv;
                 }
             }
         }
     }
+}
+
+template <bool BF, int NT>
+hipError_t launch_nt(const ConvArgs& a, int tiles, hipStream_t s) {
+    constexpr size_t shm = 3 * (2 * NPIX + 9 * 2 * 32 * NT) * sizeof(f32x4);
+    static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<BF, NT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<BF, NT>), dim3(tiles), dim3(256), shm, s, a);
+    return hipGetLastError();
 }
 
 template <bool BF>
@@ -208,18 +316,9 @@ hipError_t launch(const ConvArgs& a, hipStream_t s) {
     const int tiles = ((a.w_ + TW - 1) / TW) * ((a.h + TH - 1) / TH) * a.n;
     if (tiles <= 0) return hipSuccess;
     if (a.cin % Elem<BF>::KG) return hipErrorInvalidValue;
-    if (a.coutp == 64) {
-        constexpr int NT = 2;
-        const size_t shm = 2 * (2 * NPIX + 9 * 2 * 32 * NT) * sizeof(f32x4);
-        hipLaunchKernelGGL((conv3x3_mfma_kernel<BF, NT>), dim3(tiles), dim3(256), shm, s, a);
-    } else if (a.coutp == 32) {
-        constexpr int NT = 1;
-        const size_t shm = 2 * (2 * NPIX + 9 * 2 * 32 * NT) * sizeof(f32x4);
-        hipLaunchKernelGGL((conv3x3_mfma_kernel<BF, NT>), dim3(tiles), dim3(256), shm, s, a);
-    } else {
-        return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
+    if (a.coutp == 64) return launch_nt<BF, 2>(a, tiles, s);
+    if (a.coutp == 32) return launch_nt<BF, 1>(a, tiles, s);
+    return hipErrorInvalidValue;
 }
 
 inline uint16_t host_f2bf(float f) {  // round-to-nearest-even, NaN stays NaN
