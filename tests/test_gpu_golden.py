@@ -1,0 +1,163 @@
+"""GPU: the HIP path (through the C ABI) against the committed golden vectors and against the
+oracle wrapper end to end.  fp32 tolerance = BASELINE.json's north-star criterion (1e-3 max abs on
+the float image); the uint8 image may differ by one LSB where the float value sits on a rounding tie."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+import make_golden as G  # noqa: E402
+
+from neural_enhanced_super_resolution_amd import RealESRGANer, RRDBNet, conv3x3  # noqa: E402
+from neural_enhanced_super_resolution_amd.synth import synthetic_frame, synthetic_state_dict  # noqa: E402
+
+TOL = 1e-3
+
+
+def test_conv_layers_vs_golden(cuda_device, golden_dir):
+    g = np.load(os.path.join(golden_dir, "conv_layers.npz"))
+    for cin, cout in G.CONV_SHAPES:
+        x, w, b = G.conv_case(cin, cout)
+        xt, wt, bt = torch.from_numpy(x).to(cuda_device), torch.from_numpy(w), torch.from_numpy(b)
+        assert np.abs(conv3x3(xt, wt, bt).cpu().numpy() - g[f"y_{cin}_{cout}"]).max() < 2e-5
+        assert np.abs(conv3x3(xt, wt, bt, lrelu=True).cpu().numpy() - g[f"ylrelu_{cin}_{cout}"]).max() < 2e-5
+    x, w, b = G.conv_case(64, 64)
+    got = conv3x3(torch.from_numpy(x).to(cuda_device), torch.from_numpy(w), torch.from_numpy(b), lrelu=True, upsample=True)
+    assert np.abs(got.cpu().numpy() - g["yup_64_64"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("mode", sorted(G.NET_MODES))
+def test_mininet_vs_golden(cuda_device, golden_dir, mode):
+    g = np.load(os.path.join(golden_dir, "mininet.npz"))
+    cin, scale = G.NET_MODES[mode]
+    net = RRDBNet(cin, 3, scale=scale, num_block=2)
+    net.load_state_dict(synthetic_state_dict(seed=3, num_in_ch=cin, scale=scale, num_block=2))
+    net.to(cuda_device)
+    for (h, w) in ((32, 48), (34, 46)):
+        y = net(torch.from_numpy(G.net_input(cin, h, w, seed=7)).to(cuda_device)).cpu().numpy()
+        assert np.abs(y - g[f"{mode}_{h}x{w}"]).max() < 5e-5
+
+
+@pytest.mark.parametrize("mode,hw", [("x2plus", 64), ("x4plus", 32)])
+def test_fulldepth_vs_golden(cuda_device, golden_dir, mode, hw):
+    g = np.load(os.path.join(golden_dir, "fulldepth.npz"))
+    cin, scale = G.NET_MODES[mode]
+    net = RRDBNet(cin, 3, scale=scale)
+    net.load_state_dict(synthetic_state_dict(seed=0, num_in_ch=cin, scale=scale))
+    net.to(cuda_device)
+    y = net(torch.from_numpy(G.net_input(cin, hw, hw, seed=11)).to(cuda_device)).cpu().numpy()
+    err = np.abs(y - g[mode]).max()
+    print(f"{mode} full depth max abs err vs golden: {err:.3e}")
+    assert err < TOL
+
+
+def test_wrapper_cases_vs_golden(cuda_device, golden_dir):
+    g = np.load(os.path.join(golden_dir, "wrapper.npz"))
+    crop = np.load(os.path.join(golden_dir, "test_jpeg_crop_64x96_bgr.npy"))
+    sd2 = synthetic_state_dict(seed=3, num_in_ch=3, scale=2, num_block=2)
+    for name, kw, kind in G.wrapper_cases():
+        up = RealESRGANer(scale=2, model_path={"params_ema": sd2}, model=RRDBNet(3, 3, scale=2, num_block=2),
+                          half=False, device=cuda_device, **kw)
+        img = G.wrapper_input(kind, crop)
+        q, mode = up.enhance(img)
+        want = g[f"{name}_q"]
+        assert mode == str(g[f"{name}_mode"]) and q.shape == want.shape and q.dtype == want.dtype
+        lsb = 257 if q.dtype == np.uint16 else 1
+        diff = np.abs(q.astype(np.int64) - want.astype(np.int64))
+        assert diff.max() <= lsb, (name, diff.max())
+        assert (diff > 0).mean() < 1e-3, (name, (diff > 0).mean())       # ties only
+        if f"{name}_f" in g.files:
+            f, _, _ = up.enhance_float(img)
+            assert np.abs(f - g[f"{name}_f"]).max() < TOL, name
+
+
+def test_wrapper_full_depth_tiled_vs_golden(cuda_device, golden_dir):
+    g = np.load(os.path.join(golden_dir, "wrapper.npz"))
+    crop = np.load(os.path.join(golden_dir, "test_jpeg_crop_64x96_bgr.npy"))
+    sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=2)
+    up = RealESRGANer(scale=2, model_path={"params_ema": sd}, model=RRDBNet(3, 3, scale=2), tile=32, tile_pad=10, pre_pad=0,
+                      half=False, device=cuda_device)
+    q, _ = up.enhance(crop)
+    assert np.abs(q.astype(int) - g["full23_tile32_q"].astype(int)).max() <= 1
+
+
+def test_x4plus_wrapper_vs_golden(cuda_device, golden_dir):
+    g = np.load(os.path.join(golden_dir, "wrapper.npz"))
+    crop = np.load(os.path.join(golden_dir, "test_jpeg_crop_64x96_bgr.npy"))
+    sd4 = synthetic_state_dict(seed=3, num_in_ch=3, scale=4, num_block=2)
+    up = RealESRGANer(scale=4, model_path={"params": sd4}, model=RRDBNet(3, 3, scale=4, num_block=2), tile=16, tile_pad=4,
+                      pre_pad=3, device=cuda_device)
+    q, _ = up.enhance(np.ascontiguousarray(crop[:24, :40]))
+    assert q.shape == (96, 160, 3)
+    assert np.abs(q.astype(int) - g["x4_tile16_q"].astype(int)).max() <= 1
+
+
+def test_fused_u8_path_equals_float_path(cuda_device):
+    """enhance() takes the fused u8 kernel path for plain 8-bit BGR frames; it must produce the
+    bytes of the float path (same arithmetic, quantiser folded into conv_last's epilogue)."""
+    sd = synthetic_state_dict(seed=3, num_in_ch=3, scale=2, num_block=2)
+    up = RealESRGANer(scale=2, model_path={"params_ema": sd}, model=RRDBNet(3, 3, scale=2, num_block=2), tile=0, pre_pad=0,
+                      device=cuda_device)
+    img = synthetic_frame(40, 56, seed=9)
+    assert up._fused_u8_ok(img)
+    fused, _ = up.enhance(img)
+    f, _, _ = up.enhance_float(img)
+    assert np.array_equal(fused, (f * 255.0).round().astype(np.uint8))
+
+
+def test_nesr_style_direct_model_call_and_truncating_quantiser(cuda_device):
+    """nesr/nesr.py:845-903: builds a 12-channel input, calls upscaler.model(x) directly and
+    quantises with clip(x*255).astype(uint8) (truncation)."""
+    from oracle.rrdbnet_ref import RRDBNetRef
+    sd = synthetic_state_dict(seed=2, num_in_ch=12, scale=4, num_block=2)
+    model = RRDBNet(num_in_ch=12, num_out_ch=3, num_feat=64, num_block=2, num_grow_ch=32)
+    up = RealESRGANer(scale=2, model_path={"params_ema": sd}, model=model, tile=0, tile_pad=0, pre_pad=0, half=False,
+                      device="cuda")
+    ref = RRDBNetRef(12, 3, scale=4, num_block=2)
+    ref.load_state_dict(sd)
+    rgb = synthetic_frame(24, 36, seed=4)
+    t = torch.from_numpy(np.transpose(rgb[:, :, ::-1].copy(), (2, 0, 1))).float() / 255.0
+    x12 = torch.cat([t, torch.clamp(t * 1.1, 0, 1), torch.clamp(t * 0.9, 0, 1), t], 0).unsqueeze(0)   # nesr.py:860-879 (blur slot = identity here)
+    with torch.no_grad():
+        m = up.model
+        m.eval()
+        out = m(x12.to("cuda")).squeeze().cpu().numpy()
+        want = ref(x12).squeeze().numpy()
+    assert out.shape == (3, 96, 144)
+    assert np.abs(out - want).max() < TOL
+    q = np.clip(np.transpose(out, (1, 2, 0)) * 255.0, 0, 255).astype(np.uint8)
+    qw = np.clip(np.transpose(want, (1, 2, 0)) * 255.0, 0, 255).astype(np.uint8)
+    assert np.abs(q.astype(int) - qw.astype(int)).max() <= 1
+
+
+def test_linearity_property_at_full_size(cuda_device):
+    """Size-independent property at BASELINE's full C2 size (the oracle takes seconds there, so
+    this does not call it): one conv layer is linear, conv(a*x + b*y) == a*conv(x) + b*conv(y)
+    (bias handled), on a 256x256x64 feature map."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 64, 256, 256, generator=g).to(cuda_device)
+    y = torch.randn(1, 64, 256, 256, generator=g).to(cuda_device)
+    w = torch.randn(64, 64, 3, 3, generator=g) * 0.05
+    b = torch.zeros(64)
+    lhs = conv3x3(1.5 * x - 0.5 * y, w, b)
+    rhs = 1.5 * conv3x3(x, w, b) - 0.5 * conv3x3(y, w, b)
+    assert (lhs - rhs).abs().max().item() < 1e-4
+
+
+def test_translation_property_full_net(cuda_device):
+    """Away from borders the network commutes with translation by a whole trunk pixel: shifting
+    the input by 2 px shifts the x2 output by 4 px (exact same arithmetic per pixel -> bit equal)."""
+    sd = synthetic_state_dict(seed=3, num_in_ch=3, scale=2, num_block=1)
+    net = RRDBNet(3, 3, scale=2, num_block=1)
+    net.load_state_dict(sd)
+    net.to(cuda_device)
+    x = torch.rand(1, 3, 128, 160, generator=torch.Generator().manual_seed(1)).to(cuda_device)
+    y0 = net(x)
+    y1 = net(torch.roll(x, shifts=(2, 2), dims=(2, 3)))
+    m = 88   # > receptive-field radius of the 1-block net at output resolution (17 trunk px * 4 + upsampler convs)
+    assert torch.equal(y1[:, :, m + 4:-m, m + 4:-m], y0[:, :, m:-m - 4, m:-m - 4])

@@ -1,0 +1,152 @@
+"""CPU: the product's host-side wrapper logic (padding, tile grid, crop, colour order, quantisation)
+against the oracle wrapper, with the SAME injected CPU network on both sides -- so any difference
+is host logic, not arithmetic.  (The product never imports the oracle; the test injects it, the way
+upstream's RealESRGANer accepts any nn.Module as ``model``.)"""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from neural_enhanced_super_resolution_amd import RealESRGANer, RRDBNet
+from neural_enhanced_super_resolution_amd.synth import synthetic_frame, synthetic_state_dict
+from oracle.realesrganer_ref import RealESRGANerRef
+from oracle.rrdbnet_ref import RRDBNetRef
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "oracle"))
+import make_golden as G  # noqa: E402
+
+
+class Nearest(torch.nn.Module):
+    """A cheap stand-in network: nearest-neighbour upsample by `s` plus a position-dependent
+    term, so misplaced tiles or crops show up exactly."""
+
+    def __init__(self, s):
+        super().__init__()
+        self.s = s
+        self.p = torch.nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        y = torch.nn.functional.interpolate(x, scale_factor=self.s, mode="nearest")
+        return y * 0.9 + 0.05
+
+
+def _both(scale_net, kw, sd=None, num_block=1):
+    if sd is None:
+        mk = lambda: Nearest(scale_net)   # noqa: E731
+        ours = RealESRGANer(scale=scale_net, model_path={"params": {"p": torch.zeros(1)}}, model=mk(), device="cpu", **kw)
+        ref = RealESRGANerRef(scale=scale_net, model_path={"params": {"p": torch.zeros(1)}}, model=mk(), **kw)
+    else:
+        up = {2: 2, 4: 4}[scale_net]
+        ours = RealESRGANer(scale=scale_net, model_path={"params_ema": sd}, model=RRDBNetRef(3, 3, scale=up, num_block=num_block), device="cpu", **kw)
+        ref = RealESRGANerRef(scale=scale_net, model_path={"params_ema": sd}, model=RRDBNetRef(3, 3, scale=up, num_block=num_block), **kw)
+    return ours, ref
+
+
+@pytest.mark.parametrize("scale", [2, 4])
+@pytest.mark.parametrize("kw", [dict(tile=0, tile_pad=10, pre_pad=0), dict(tile=0, tile_pad=10, pre_pad=10),
+                                dict(tile=32, tile_pad=10, pre_pad=0), dict(tile=24, tile_pad=3, pre_pad=7),
+                                dict(tile=512, tile_pad=10, pre_pad=0)])
+@pytest.mark.parametrize("hw", [(64, 96), (63, 95), (33, 47), (2, 70), (5, 71)])
+def test_enhance_matches_oracle_wrapper_bitwise(scale, kw, hw):
+    if kw["pre_pad"] >= min(hw):
+        pytest.skip("reflect pad larger than the image is an error upstream too")
+    img = synthetic_frame(hw[0], hw[1], seed=hw[0])
+    ours, ref = _both(scale, kw)
+    a, ma = ours.enhance(img)
+    b, mb = ref.enhance(img)
+    assert ma == mb == "RGB"
+    assert a.shape == (hw[0] * scale, hw[1] * scale, 3)
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("tile_batch", [1, 3, 8])
+def test_tile_batching_is_value_preserving(tile_batch):
+    sd = synthetic_state_dict(seed=3, num_in_ch=3, scale=2, num_block=1)
+    ours, ref = _both(2, dict(tile=32, tile_pad=10, pre_pad=0), sd=sd)
+    ours.tile_batch = tile_batch
+    img = synthetic_frame(70, 100, seed=1)
+    fa, _, _ = ours.enhance_float(img)
+    fb, _, _ = ref.enhance_float(img)
+    assert np.abs(fa - fb).max() < 1e-5          # batched conv on CPU may reorder sums; values must agree
+    qa, _ = ours.enhance(img)
+    qb, _ = ref.enhance(img)
+    assert np.abs(qa.astype(int) - qb.astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("kind", ["gray", "bgra", "u16"])
+def test_image_modes_match_oracle(kind, golden_dir):
+    crop = np.load(os.path.join(golden_dir, "test_jpeg_crop_64x96_bgr.npy"))
+    img = G.wrapper_input(kind, crop)
+    ours, ref = _both(2, dict(tile=32, tile_pad=10, pre_pad=0))
+    a, ma = ours.enhance(img)
+    b, mb = ref.enhance(img)
+    assert ma == mb == {"gray": "L", "bgra": "RGBA", "u16": "RGB"}[kind]
+    assert a.dtype == b.dtype and np.array_equal(a, b)
+
+
+def test_tile_grid_is_upstreams_c3_grid():
+    """3840x2160 with tile=512/tile_pad=10 -> 8x5 = 40 tiles, interior 532^2."""
+    up = RealESRGANer.__new__(RealESRGANer)
+    up.scale, up.tile_size, up.tile_pad = 2, 512, 10
+    grid = up.tile_grid(2160, 3840)
+    assert len(grid) == math.ceil(2160 / 512) * math.ceil(3840 / 512) == 40
+    shapes = [(g[0][1] - g[0][0], g[0][3] - g[0][2]) for g in grid]
+    assert shapes.count((532, 532)) == 18 and max(shapes) == (532, 532)
+    assert shapes[0] == (522, 522) and shapes[-1] == (122, 266)
+    # output windows tile the canvas exactly once
+    canvas = np.zeros((4320, 7680), np.int32)
+    for _, (oy0, oy1, ox0, ox1), (cy0, cy1, cx0, cx1) in grid:
+        assert (oy1 - oy0, ox1 - ox0) == (cy1 - cy0, cx1 - cx0)
+        canvas[oy0:oy1, ox0:ox1] += 1
+    assert (canvas == 1).all()
+
+
+def test_declared_scale_is_adapted_for_x2plus_checkpoint():
+    """direct_esrgan.py:104 declares RRDBNet(num_in_ch=3) without scale=2 and loads x2plus weights
+    (12-ch conv_first): upstream fails strict loading; the drop-in recognises the checkpoint."""
+    sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=2, num_block=1)
+    net = RRDBNet(num_in_ch=3, num_out_ch=3, num_feat=64, num_block=1, num_grow_ch=32)
+    with pytest.warns(UserWarning, match="scale=2"):
+        up = RealESRGANer(scale=2, model_path={"params_ema": sd}, model=net, tile=512, tile_pad=10, pre_pad=0, half=False, device="cpu")
+    assert up.model.scale == 2 and up.model.conv_first.weight.shape[1] == 12
+    assert torch.equal(up.model.state_dict()["conv_first.weight"], sd["conv_first.weight"])
+
+
+def test_checkpoint_file_roundtrip(tmp_path):
+    sd = synthetic_state_dict(seed=1, num_in_ch=12, scale=4, num_block=1)
+    p = tmp_path / "RealESRGAN_x2plus.pth"
+    torch.save({"params_ema": sd, "params": {k: v * 0 for k, v in sd.items()}}, p)
+    net = RRDBNet(num_in_ch=12, num_out_ch=3, num_feat=64, num_block=1, num_grow_ch=32)   # nesr/nesr.py:216
+    up = RealESRGANer(scale=2, model_path=str(p), model=net, tile=0, tile_pad=0, pre_pad=0, half=False, device="cpu")
+    assert torch.equal(up.model.body[0].rdb2.conv3.weight, sd["body.0.rdb2.conv3.weight"])   # params_ema preferred
+
+
+def test_missing_key_is_an_error():
+    sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=2, num_block=1)
+    sd.pop("conv_up2.weight")
+    with pytest.raises(RuntimeError, match="conv_up2.weight"):
+        RealESRGANer(scale=2, model_path={"params": sd}, model=RRDBNet(3, 3, scale=2, num_block=1), device="cpu")
+
+
+def test_dni_interpolates_checkpoints():
+    a = {"params": synthetic_state_dict(seed=0, num_in_ch=3, scale=2, num_block=1)}
+    b = {"params": synthetic_state_dict(seed=1, num_in_ch=3, scale=2, num_block=1)}
+    want = 0.25 * a["params"]["conv_hr.weight"] + 0.75 * b["params"]["conv_hr.weight"]
+    up = RealESRGANer(scale=2, model_path=[a, b], dni_weight=[0.25, 0.75], model=RRDBNet(3, 3, scale=2, num_block=1), device="cpu")
+    assert torch.allclose(up.model.conv_hr.weight, want)
+
+
+def test_product_forward_has_no_cpu_fallback():
+    net = RRDBNet(3, 3, scale=2, num_block=1)
+    up = RealESRGANer(scale=2, model_path={"params": synthetic_state_dict(0, 3, 3, 2, 64, 1, 32)}, model=net, device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU"):
+        up.enhance(synthetic_frame(16, 16))
+
+
+def test_https_model_path_is_refused_offline():
+    with pytest.raises(RuntimeError, match="not supported"):
+        RealESRGANer(scale=2, model_path="https://github.com/xinntao/Real-ESRGAN/releases/download/v0.2.5.0/x.pth",
+                     model=RRDBNet(3, 3, scale=2, num_block=1), device="cpu")
