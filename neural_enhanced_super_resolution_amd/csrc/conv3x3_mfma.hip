@@ -26,6 +26,8 @@
 //               clamped/quantised u8 HWC store for conv_last.
 #include <hip/hip_bf16.h>
 
+#include <cstdlib>
+
 #include "nesr_kernels.h"
 
 namespace nesr {
@@ -360,6 +362,18 @@ void pack_weights_bf16(const float* oihw, int cout, int cin, int cin_p, int cout
 }
 
 hipError_t launch_conv3x3_f32(const ConvArgs& a, hipStream_t s) { return launch<false>(a, s); }
-hipError_t launch_conv3x3_bf16(const ConvArgs& a, hipStream_t s) { return launch<true>(a, s); }
+// bf16: frames of at least 128x128 trunk pixels take the large-tile LDS-DMA kernel; the choice
+// depends on the frame size only (never on the batch), so a tile's arithmetic is the same on every
+// rank and in every batch.  NESR_BF16_KERNEL=small|big overrides (tests, A/B timing).
+hipError_t launch_conv3x3_bf16(const ConvArgs& a, hipStream_t s) {
+    static const int mode = [] {
+        const char* e = getenv("NESR_BF16_KERNEL");
+        if (!e) return 0;
+        return e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : 0);
+    }();
+    const bool big = mode == 2 || (mode == 0 && (long)a.h * a.w_ >= 128L * 128L);
+    if (big && a.zeros) return launch_conv3x3_bf16_big(a, s);
+    return launch<true>(a, s);
+}
 
 }  // namespace nesr

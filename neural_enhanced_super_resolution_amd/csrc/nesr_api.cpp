@@ -55,7 +55,7 @@ struct nesr_ctx {
     std::vector<Layer> layers;
     std::unordered_map<std::string, int> index;
     bool finalized = false;
-    char* d_weights = nullptr;
+    char* d_weights = nullptr;   // arena: [256 B of zeros | packed weights and biases]
     char* ws = nullptr;
     size_t ws_bytes = 0;
     // kernel timing hook
@@ -120,9 +120,10 @@ hipError_t launch_conv(const nesr_ctx* c, const ConvArgs& a, hipStream_t s) {
     return c->dtype == NESR_DTYPE_BF16 ? launch_conv3x3_bf16(a, s) : launch_conv3x3_f32(a, s);
 }
 
-ConvArgs base_args(const Layer& L, int N, int h, int w) {
+ConvArgs base_args(const nesr_ctx* c, const Layer& L, int N, int h, int w) {
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
+    a.zeros = c->d_weights;
     a.cin = L.cin_p;
     a.w = L.d_w;
     a.bias = L.d_b;
@@ -172,7 +173,7 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
 
     // conv_first: IN -> A.x0 and F (feat is needed again after the trunk)
     {
-        ConvArgs a = base_args(c->layers[0], N, h, w);
+        ConvArgs a = base_args(c, c->layers[0], N, h, w);
         a.in = ws + L.in; a.in_stride = c->layers[0].cin_p;
         a.out = ws + L.a; a.out_stride = ct; a.out_coff = 0;
         a.out2 = ws + L.f; a.out2_stride = nf;
@@ -200,7 +201,7 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
             char* cur = buf[r];
             for (int k = 0; k < 4; ++k) {
                 const Layer& Ly = c->layers[layer_id(c, b, r, k)];
-                ConvArgs a = base_args(Ly, N, h, w);
+                ConvArgs a = base_args(c, Ly, N, h, w);
                 a.in = cur; a.in_stride = ct;
                 a.out = cur; a.out_stride = ct; a.out_coff = nf + k * gc;
                 a.lrelu = 1;
@@ -208,7 +209,7 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
                 if (c->timing) c->timed_flops += conv_flops(Ly, px);
             }
             const Layer& L5 = c->layers[layer_id(c, b, r, 4)];
-            ConvArgs a = base_args(L5, N, h, w);
+            ConvArgs a = base_args(c, L5, N, h, w);
             a.in = cur; a.in_stride = ct;
             a.res1 = cur; a.res1_stride = ct; a.s1 = 0.2f;
             if (r < 2) {
@@ -231,7 +232,7 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
     const int tail = 1 + c->nb * 15;
     // feat = feat + conv_body(trunk)   (in place on F)
     {
-        ConvArgs a = base_args(c->layers[tail], N, h, w);
+        ConvArgs a = base_args(c, c->layers[tail], N, h, w);
         a.in = buf[0]; a.in_stride = ct;
         a.out = ws + L.f; a.out_stride = nf;
         a.res1 = ws + L.f; a.res1_stride = nf; a.s1 = 1.0f;
@@ -239,28 +240,28 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
     }
     // lrelu(conv_up1(nearest2x(feat)))
     {
-        ConvArgs a = base_args(c->layers[tail + 1], N, 2 * h, 2 * w);
+        ConvArgs a = base_args(c, c->layers[tail + 1], N, 2 * h, 2 * w);
         a.in = ws + L.f; a.in_stride = nf; a.in_h = h; a.in_w = w; a.up = 1;
         a.out = ws + L.u1; a.out_stride = nf; a.lrelu = 1;
         HIP_TRY(launch_conv(c, a, s));
     }
     // lrelu(conv_up2(nearest2x(feat)))
     {
-        ConvArgs a = base_args(c->layers[tail + 2], N, 4 * h, 4 * w);
+        ConvArgs a = base_args(c, c->layers[tail + 2], N, 4 * h, 4 * w);
         a.in = ws + L.u1; a.in_stride = nf; a.in_h = 2 * h; a.in_w = 2 * w; a.up = 1;
         a.out = ws + L.u2; a.out_stride = nf; a.lrelu = 1;
         HIP_TRY(launch_conv(c, a, s));
     }
     // lrelu(conv_hr(feat))
     {
-        ConvArgs a = base_args(c->layers[tail + 3], N, 4 * h, 4 * w);
+        ConvArgs a = base_args(c, c->layers[tail + 3], N, 4 * h, 4 * w);
         a.in = ws + L.u2; a.in_stride = nf;
         a.out = ws + L.u3; a.out_stride = nf; a.lrelu = 1;
         HIP_TRY(launch_conv(c, a, s));
     }
     // conv_last -> planar f32 NCHW, or clamped + quantised u8 HWC
     {
-        ConvArgs a = base_args(c->layers[tail + 4], N, 4 * h, 4 * w);
+        ConvArgs a = base_args(c, c->layers[tail + 4], N, 4 * h, 4 * w);
         a.in = ws + L.u3; a.in_stride = nf;
         a.cout_real = c->nout;
         a.out_nchw = y_f32;
@@ -370,7 +371,7 @@ int nesr_finalize_weights(nesr_ctx* c) {
     if (nmiss) return fail(NESR_ERR_STATE, "Missing key(s) in state_dict (" + std::to_string(nmiss) + "):" + missing);
     HIP_TRY(hipSetDevice(c->device));
     const bool bf = c->dtype == NESR_DTYPE_BF16;
-    size_t total = 0;
+    size_t total = 256;   // leading zero page
     std::vector<size_t> woff(c->layers.size()), boff(c->layers.size());
     for (size_t i = 0; i < c->layers.size(); ++i) {
         const Layer& L = c->layers[i];
@@ -506,13 +507,15 @@ int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, in
         pack_weights_f32(w_host, Cout, Cin, cin_p, cout_p, reinterpret_cast<float*>(hw.data()));
     std::vector<float> hb(cout_p, 0.f);
     std::memcpy(hb.data(), b_host, (size_t)Cout * 4);
-    char *d_w = nullptr, *d_in = nullptr, *d_out = nullptr;
+    char *d_w = nullptr, *d_in = nullptr, *d_out = nullptr, *d_zero = nullptr;
     float* d_b = nullptr;
     const size_t in_bytes = (size_t)N * H * W * cin_p * es, out_bytes = (size_t)N * ho * wo * cout_p * es;
     HIP_TRY(hipMalloc((void**)&d_w, hw.size()));
     HIP_TRY(hipMalloc((void**)&d_b, hb.size() * 4));
     HIP_TRY(hipMalloc((void**)&d_in, in_bytes));
     HIP_TRY(hipMalloc((void**)&d_out, out_bytes));
+    HIP_TRY(hipMalloc((void**)&d_zero, 256));
+    HIP_TRY(hipMemset(d_zero, 0, 256));
     HIP_TRY(hipMemcpy(d_w, hw.data(), hw.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
     PackArgs p;
@@ -526,10 +529,11 @@ int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, in
     a.n = N; a.h = ho; a.w_ = wo;
     a.out = d_out; a.out_stride = cout_p; a.out_coff = 0;
     a.lrelu = lrelu ? 1 : 0; a.s1 = a.s2 = 1.f;
+    a.zeros = d_zero;
     HIP_TRY(bf ? launch_conv3x3_bf16(a, s) : launch_conv3x3_f32(a, s));
     HIP_TRY(launch_nhwc_to_nchw(d_out, bf, cout_p, N, Cout, ho, wo, static_cast<float*>(y_dev), s));
     HIP_TRY(hipStreamSynchronize(s));
-    (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_in); (void)hipFree(d_out);
+    (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_zero);
     return NESR_OK;
 }
 

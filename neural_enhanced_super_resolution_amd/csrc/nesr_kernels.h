@@ -38,6 +38,8 @@ struct ConvArgs {
     // fused image output: u8 HWC [h][w][3], clamp(0,1) * 255, optional channel flip
     uint8_t* out_u8;
     int u8_flip, u8_round;
+    // >= 16 bytes of device zeros: LDS-DMA source for out-of-image pixels (bf16 large-tile kernel)
+    const void* zeros;
 };
 
 // f32 path: v_mfma_f32_32x32x2_f32 implicit GEMM (conv3x3_f32.hip)
@@ -47,7 +49,8 @@ size_t packed_weight_elems_f32(int cin_p, int coutp);
 void pack_weights_f32(const float* oihw, int cout, int cin, int cin_p, int coutp, float* dst);
 
 // bf16 path: v_mfma_f32_32x32x16_bf16 implicit GEMM (conv3x3_bf16.hip)
-hipError_t launch_conv3x3_bf16(const ConvArgs& a, hipStream_t s);
+hipError_t launch_conv3x3_bf16(const ConvArgs& a, hipStream_t s);       // picks the variant by frame size
+hipError_t launch_conv3x3_bf16_big(const ConvArgs& a, hipStream_t s);   // conv3x3_bf16.hip: 16x32-px tiles, LDS-DMA
 size_t packed_weight_elems_bf16(int cin_p, int coutp);
 void pack_weights_bf16(const float* oihw, int cout, int cin, int cin_p, int coutp, uint16_t* dst);
 

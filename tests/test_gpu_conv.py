@@ -77,3 +77,41 @@ def test_conv3x3_bf16_matches_bf16_rounded_reference(cuda_device, cin, cout):
     got = conv3x3(x.to(cuda_device), w, b, dtype="bf16").cpu()
     scale = max(1.0, ref.abs().max().item())
     assert (got - ref).abs().max().item() < 2 ** -7 * scale   # output stored as bf16 (8 bits of mantissa)
+
+
+BIG = (136, 160)   # >= 128*128 trunk pixels: the bf16 path takes the large-tile LDS-DMA kernel
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 64), (64, 32), (96, 32), (160, 32), (192, 64), (64, 64), (64, 3)])
+def test_conv3x3_bf16_big_tile_kernel(cuda_device, cin, cout):
+    from neural_enhanced_super_resolution_amd import conv3x3
+    x, w, b = _case(cin, cout, BIG[0], BIG[1], seed=3 * cin + cout, n=2)
+    ref = F.leaky_relu(F.conv2d(x.bfloat16().float(), w.bfloat16().float(), b, padding=1), 0.2)
+    got = conv3x3(x.to(cuda_device), w, b, lrelu=True, dtype="bf16").cpu()
+    scale = max(1.0, ref.abs().max().item())
+    assert (got - ref).abs().max().item() < 2 ** -7 * scale
+
+
+def test_conv3x3_bf16_big_tile_one_hot_taps(cuda_device):
+    """Exact one-hot check of the large-tile kernel's tap / row-reuse / channel bookkeeping
+    (small integers are exact in bf16)."""
+    from neural_enhanced_super_resolution_amd import conv3x3
+    cin, cout = 32, 64
+    h, w = 130, 131
+    x = ((torch.arange(cin * h * w, dtype=torch.float32).reshape(1, cin, h, w) * 7) % 61).contiguous()
+    for tap in range(9):
+        wt = torch.zeros(cout, cin, 3, 3)
+        for o in range(cout):
+            wt[o, (o * 5 + tap) % cin, tap // 3, tap % 3] = 1.0
+        b = torch.arange(cout, dtype=torch.float32)
+        ref = F.conv2d(x, wt, b, padding=1)
+        got = conv3x3(x.to(cuda_device), wt, b, dtype="bf16").cpu()
+        assert torch.equal(got, ref), f"tap {tap}"
+
+
+def test_conv3x3_bf16_big_tile_upsample(cuda_device):
+    from neural_enhanced_super_resolution_amd import conv3x3
+    x, wgt, b = _case(64, 64, 70, 90, seed=8)
+    ref = F.conv2d(F.interpolate(x.bfloat16().float(), scale_factor=2, mode="nearest"), wgt.bfloat16().float(), b, padding=1)
+    got = conv3x3(x.to(cuda_device), wgt, b, upsample=True, dtype="bf16").cpu()
+    assert (got - ref).abs().max().item() < 2 ** -7 * max(1.0, ref.abs().max().item())

@@ -96,3 +96,16 @@ def test_bf16_mininet_psnr(cuda_device):
     psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
     print("bf16 2-block PSNR vs f32 oracle: %.1f dB, max abs %.3e" % (psnr, (got - want).abs().max().item()))
     assert psnr > 35.0
+
+
+def test_bf16_big_tile_mininet_psnr_and_batch(cuda_device):
+    """Frames of >= 128x128 trunk pixels run the large-tile bf16 kernel end to end."""
+    ours, ref = _pair(3, 2, num_block=2, seed=3, compute_dtype="bf16")
+    x = torch.rand(2, 3, 288, 272, generator=torch.Generator().manual_seed(7))
+    want = ref(x)
+    got = ours(x.to(cuda_device)).cpu()
+    mse = ((got - want) ** 2).mean().item()
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
+    print("bf16 big-tile 2-block PSNR vs f32 oracle: %.1f dB" % psnr)
+    assert psnr > 35.0
+    assert torch.equal(ours(x[1:2].to(cuda_device)).cpu(), got[1:2])     # batch-independent arithmetic
