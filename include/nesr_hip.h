@@ -107,6 +107,10 @@ double nesr_forward_flops(const nesr_ctx* ctx, int N, int H, int W);
 int nesr_set_kernel_timing(nesr_ctx* ctx, int enable);
 int nesr_kernel_time_ms(nesr_ctx* ctx, double* total_ms, int64_t* launches, double* flops);
 
+/* Waits for the device and reports deferred failures of asynchronous work (the persistent trunk
+ * kernel bounds every inter-workgroup wait and sets an abort word instead of hanging). */
+int nesr_check_status(nesr_ctx* ctx);
+
 void nesr_destroy(nesr_ctx* ctx);
 
 /*

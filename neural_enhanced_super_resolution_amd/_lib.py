@@ -30,6 +30,7 @@ SIGNATURES = {
     "nesr_forward_flops": (_c.c_double, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int]),
     "nesr_set_kernel_timing": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "nesr_kernel_time_ms": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_double)]),
+    "nesr_check_status": (_c.c_int, [_c.c_void_p]),
     "nesr_destroy": (None, [_c.c_void_p]),
     "nesr_conv3x3": (_c.c_int, [_c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
                                 _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),

@@ -67,11 +67,12 @@ struct Elem<true> {
     }
 };
 
+// One output tile (8 x 16 pixels at (y0, x0) of image n) of one convolution.  Shared by the
+// per-layer kernel below and by the persistent trunk kernel (trunk_persist.hip).
 template <bool BF, int NT>
-__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_tile(const ConvArgs& a, const int n, const int y0, const int x0, char* smem) {
     typedef typename Elem<BF>::T T;
     constexpr int KG = Elem<BF>::KG;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int IN_F4 = 2 * NPIX;
     constexpr int W_F4 = 9 * 2 * 32 * NT;
     constexpr int STAGE_F4 = IN_F4 + W_F4;
@@ -80,13 +81,6 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int tiles_x = (a.w_ + TW - 1) / TW;
-    const int tiles_y = (a.h + TH - 1) / TH;
-    int bid = blockIdx.x;
-    const int n = bid / (tiles_x * tiles_y);
-    bid -= n * tiles_x * tiles_y;
-    const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
-    const int y0 = ty * TH, x0 = tx * TW;
 
     // ---- staging assignment, fixed across chunks and branch-free.  One chunk's LDS image is
     // [input: 2 planes x 180 pixels | weights: 9 taps x 2 halves x 32*NT] 16-byte items; item k of
@@ -151,6 +145,13 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // bias is fetched now so its latency hides under the K loop
+    f32x4 bs[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bs[t][g] = *reinterpret_cast<const f32x4*>(a.bias + t * 32 + 8 * g + 4 * hh);
 
     const int nchunks = a.cin / KG;
     // operand registers: a 3-slot rotation, tap t lives in slot t % 3 and is read two taps ahead
@@ -219,11 +220,7 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
     const int Y = y0 + prow, X = x0 + pcol;
     const bool valid = Y < a.h && X < a.w_;
     const size_t pix = ((size_t)n * a.h + (valid ? Y : 0)) * a.w_ + (valid ? X : 0);
-    f32x4 r1[NT][4], r2[NT][4], bs[NT][4];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bs[t][g] = *reinterpret_cast<const f32x4*>(a.bias + t * 32 + 8 * g + 4 * hh);
+    f32x4 r1[NT][4], r2[NT][4];
     if (a.res1) {
         const T* rp = static_cast<const T*>(a.res1) + pix * a.res1_stride + 4 * hh;
 #pragma unroll
@@ -300,6 +297,23 @@ __global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
 }
 
 template <bool BF, int NT>
+__global__ __launch_bounds__(256) void conv3x3_mfma_kernel(ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tiles_x = (a.w_ + TW - 1) / TW;
+    const int tiles_y = (a.h + TH - 1) / TH;
+    int bid = blockIdx.x;
+    const int n = bid / (tiles_x * tiles_y);
+    bid -= n * tiles_x * tiles_y;
+    const int ty = bid / tiles_x, tx = bid - ty * tiles_x;
+#ifdef NESR_STAGGER
+    // de-phase the two workgroups that share a CU (they are dispatched half a grid apart): without
+    // it both hit every chunk barrier together and the MFMA pipe idles (MI355X_MICROARCH.md item 9)
+    if (blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_sleep(NESR_STAGGER);
+#endif
+    conv_tile<BF, NT>(a, n, ty * TH, tx * TW, smem);
+}
+
+template <bool BF, int NT>
 hipError_t launch_nt(const ConvArgs& a, int tiles, hipStream_t s) {
     constexpr size_t shm = 3 * (2 * NPIX + 9 * 2 * 32 * NT) * sizeof(f32x4);
     static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
@@ -321,6 +335,146 @@ hipError_t launch(const ConvArgs& a, hipStream_t s) {
     if (a.coutp == 64) return launch_nt<BF, 2>(a, tiles, s);
     if (a.coutp == 32) return launch_nt<BF, 1>(a, tiles, s);
     return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------
+// Persistent trunk kernel.  Layer L of tile t may start once its 8 neighbouring tiles have
+// completed layers < L (their outputs are this tile's halo).  That single condition also covers
+// every write-after-read on the rotating buffers: neighbouring tiles are never more than one
+// layer apart, and no layer writes a channel slice the previous layer reads.
+// Hand-off (cdna_hip_programming.md Guideline 16): producer = plain stores, every wave
+// s_waitcnt vmcnt(0), workgroup barrier, one lane agent-scope release + vmcnt(0) + relaxed agent
+// store of the counter; consumer = one wave polls relaxed, ONE agent-scope acquire, vmcnt(0),
+// workgroup barrier, then plain loads.  Placement independent; every spin is bounded.
+constexpr size_t TRUNK_RING_BYTES = 3 * (2 * NPIX + 9 * 2 * 32 * 2) * sizeof(f32x4);
+constexpr size_t TRUNK_SHM = TRUNK_RING_BYTES + 16;
+
+template <bool BF>
+__global__ __launch_bounds__(256, 2) void trunk_persist_kernel(TrunkArgs t) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    volatile unsigned* s_abort = reinterpret_cast<volatile unsigned*>(smem + TRUNK_RING_BYTES);
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (t.w + TW - 1) / TW;
+    const int tiles_y = (t.h + TH - 1) / TH;
+    const int per_img = tiles_x * tiles_y;
+    const int ntiles = per_img * t.n;
+    if (tid == 0) *s_abort = 0;
+    __syncthreads();
+
+    for (int L = 0; L < t.nlayers; ++L) {
+        const TrunkLayer ly = t.layers[L];
+        ConvArgs a;
+        a.in = t.buf[ly.in_buf];
+        a.in_stride = t.stride;
+        a.in_h = t.h;
+        a.in_w = t.w;
+        a.up = 0;
+        a.cin = ly.cin;
+        a.w = ly.w;
+        a.bias = ly.bias;
+        a.coutp = ly.coutp;
+        a.n = t.n;
+        a.h = t.h;
+        a.w_ = t.w;
+        a.out = t.buf[ly.out_buf];
+        a.out_stride = t.stride;
+        a.out_coff = ly.out_coff;
+        a.out2 = nullptr;
+        a.out2_stride = 0;
+        a.lrelu = ly.lrelu;
+        a.res1 = ly.res1_buf >= 0 ? t.buf[ly.res1_buf] : nullptr;
+        a.res1_stride = t.stride;
+        a.s1 = ly.s1;
+        a.res2 = ly.res2_buf >= 0 ? t.buf[ly.res2_buf] : nullptr;
+        a.res2_stride = t.stride;
+        a.s2 = ly.s2;
+        a.out_nchw = nullptr;
+        a.cout_real = 0;
+        a.out_u8 = nullptr;
+        a.u8_flip = a.u8_round = 0;
+        a.zeros = t.zeros;
+
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int n = tile / per_img;
+            const int rem = tile - n * per_img;
+            const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+
+            // ---- wait for the 8 neighbours to have finished layer L-1 (bounded)
+            if (L > 0) {
+                if (wave == 0) {
+                    const int lane = tid & 63;
+                    const int dy = lane / 3 - 1, dx = lane - (lane / 3) * 3 - 1;
+                    const int ny = ty + dy, nx = tx + dx;
+                    const bool watch = lane < 9 && lane != 4 && ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x;
+                    const unsigned* ctr = t.progress + (watch ? n * per_img + ny * tiles_x + nx : tile);
+                    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                    bool aborted = false;
+                    for (;;) {
+                        const unsigned v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (__all(!watch || v >= (unsigned)L)) break;
+                        if (__hip_atomic_load(t.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ||
+                            __builtin_amdgcn_s_memrealtime() - t0 > 300000000ull) {   // 3 s at 100 MHz
+                            aborted = true;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (aborted) {
+                        if (lane == 0) {
+                            __hip_atomic_store(t.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            *s_abort = 1u;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+                if (*s_abort) return;   // uniform: every thread reads the same LDS word after the barrier
+            }
+
+            if (ly.coutp == 64)
+                conv_tile<BF, 2>(a, n, ty * TH, tx * TW, smem);
+            else
+                conv_tile<BF, 1>(a, n, ty * TH, tx * TW, smem);
+
+            // ---- publish: this tile has completed layer L
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(t.progress + tile, (unsigned)(L + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+template <bool BF>
+hipError_t launch_trunk(const TrunkArgs& t, hipStream_t s) {
+    static int max_blocks = -1;   // co-resident workgroups on this device
+    if (max_blocks < 0) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trunk_persist_kernel<BF>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRUNK_SHM);
+        if (e != hipSuccess) return e;
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trunk_persist_kernel<BF>, 256, TRUNK_SHM);
+        if (e != hipSuccess) return e;
+        if (per_cu > 2) per_cu = 2;   // LDS admits 2; never trust the API for more (MI355X_MICROARCH.md, residency)
+        if (per_cu < 1) return hipErrorLaunchOutOfResources;
+        max_blocks = per_cu * prop.multiProcessorCount;
+    }
+    const int ntiles = ((t.w + TW - 1) / TW) * ((t.h + TH - 1) / TH) * t.n;
+    if (ntiles <= 0 || t.nlayers <= 0) return hipSuccess;
+    const int grid = ntiles < max_blocks ? ntiles : max_blocks;
+    TrunkArgs targ = t;
+    void* params[] = {&targ};
+    // cooperative launch: the runtime verifies that the whole grid is co-resident
+    return hipLaunchCooperativeKernel(reinterpret_cast<const void*>(&trunk_persist_kernel<BF>), dim3(grid), dim3(256), params,
+                                      TRUNK_SHM, s);
 }
 
 inline uint16_t host_f2bf(float f) {  // round-to-nearest-even, NaN stays NaN
@@ -362,6 +516,9 @@ void pack_weights_bf16(const float* oihw, int cout, int cin, int cin_p, int cout
 }
 
 hipError_t launch_conv3x3_f32(const ConvArgs& a, hipStream_t s) { return launch<false>(a, s); }
+hipError_t launch_trunk_persist(const TrunkArgs& t, bool bf16, hipStream_t s) {
+    return bf16 ? launch_trunk<true>(t, s) : launch_trunk<false>(t, s);
+}
 // bf16: frames of at least 128x128 trunk pixels take the large-tile LDS-DMA kernel; the choice
 // depends on the frame size only (never on the batch), so a tile's arithmetic is the same on every
 // rank and in every batch.  NESR_BF16_KERNEL=small|big overrides (tests, A/B timing).

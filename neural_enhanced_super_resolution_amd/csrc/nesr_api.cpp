@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -58,6 +59,9 @@ struct nesr_ctx {
     char* d_weights = nullptr;   // arena: [256 B of zeros | packed weights and biases]
     char* ws = nullptr;
     size_t ws_bytes = 0;
+    TrunkLayer* d_trunk = nullptr;
+    unsigned* last_sync = nullptr;   // abort word of the most recent persistent launch   // device copy of the trunk's layer table (persistent trunk kernel)
+    int trunk_mode = 0;              // 0 auto, 1 per-layer launches, 2 persistent kernel
     // kernel timing hook
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
@@ -75,7 +79,8 @@ namespace {
 int layer_id(const nesr_ctx* c, int b, int r, int k) { return 1 + (b * 3 + r) * 5 + k; }  // r,k zero based
 
 struct WsLayout {
-    size_t in, f, a, b, c, u1, u2, u3, total;
+    size_t in, f, a, b, c, u1, u2, u3, sync, total;
+    int sync_words;
 };
 
 WsLayout ws_layout(const nesr_ctx* c, int N, int h, int w) {
@@ -96,6 +101,9 @@ WsLayout ws_layout(const nesr_ctx* c, int N, int h, int w) {
     L.u1 = take(px * 4 * c->nf * es);
     L.u2 = take(px * 16 * c->nf * es);
     L.u3 = take(px * 16 * c->nf * es);
+    // per-tile progress counters of the persistent trunk kernel (8x16-pixel tiles) + abort word
+    L.sync_words = N * ((h + 7) / 8) * ((w + 15) / 16) + 64;
+    L.sync = take((size_t)L.sync_words * 4);
     L.total = off;
     return L;
 }
@@ -107,6 +115,7 @@ int ensure_ws(nesr_ctx* c, size_t bytes) {
         HIP_TRY(hipFree(c->ws));
         c->ws = nullptr;
         c->ws_bytes = 0;
+        c->last_sync = nullptr;
     }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
@@ -196,31 +205,52 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
         HIP_TRY(hipEventRecord(ev0, s));
     }
     const double px = (double)N * h * w;
-    for (int b = 0; b < c->nb; ++b) {
-        for (int r = 0; r < 3; ++r) {
-            char* cur = buf[r];
-            for (int k = 0; k < 4; ++k) {
-                const Layer& Ly = c->layers[layer_id(c, b, r, k)];
-                ConvArgs a = base_args(c, Ly, N, h, w);
+    const bool persist = c->trunk_mode == 2;   // opt-in (NESR_TRUNK=persist): measured slower at 2 tiles/CU, see DESIGN.md
+    if (persist && c->nb > 0) {
+        // one cooperative launch for all 15*nb dense-block convs (tile-level dataflow sync)
+        unsigned* sync = reinterpret_cast<unsigned*>(ws + L.sync);
+        HIP_TRY(hipMemsetAsync(sync, 0, (size_t)L.sync_words * 4, s));
+        TrunkArgs t;
+        std::memset(&t, 0, sizeof(t));
+        t.layers = c->d_trunk;
+        t.nlayers = c->nb * 15;
+        t.buf[0] = buf[0]; t.buf[1] = buf[1]; t.buf[2] = buf[2];
+        t.stride = ct;
+        t.n = N; t.h = h; t.w = w;
+        t.progress = sync + 64;
+        t.abort_flag = sync;
+        t.zeros = c->d_weights;
+        HIP_TRY(launch_trunk_persist(t, bf, s));
+        c->last_sync = sync;
+        if (c->timing)
+            for (int i = 0; i < c->nb * 15; ++i) c->timed_flops += conv_flops(c->layers[1 + i], px);
+    } else {
+        for (int b = 0; b < c->nb; ++b) {
+            for (int r = 0; r < 3; ++r) {
+                char* cur = buf[r];
+                for (int k = 0; k < 4; ++k) {
+                    const Layer& Ly = c->layers[layer_id(c, b, r, k)];
+                    ConvArgs a = base_args(c, Ly, N, h, w);
+                    a.in = cur; a.in_stride = ct;
+                    a.out = cur; a.out_stride = ct; a.out_coff = nf + k * gc;
+                    a.lrelu = 1;
+                    HIP_TRY(launch_conv(c, a, s));
+                    if (c->timing) c->timed_flops += conv_flops(Ly, px);
+                }
+                const Layer& L5 = c->layers[layer_id(c, b, r, 4)];
+                ConvArgs a = base_args(c, L5, N, h, w);
                 a.in = cur; a.in_stride = ct;
-                a.out = cur; a.out_stride = ct; a.out_coff = nf + k * gc;
-                a.lrelu = 1;
+                a.res1 = cur; a.res1_stride = ct; a.s1 = 0.2f;
+                if (r < 2) {
+                    a.out = buf[r + 1];
+                } else {
+                    a.out = buf[0];
+                    a.res2 = buf[0]; a.res2_stride = ct; a.s2 = 0.2f;
+                }
+                a.out_stride = ct; a.out_coff = 0;
                 HIP_TRY(launch_conv(c, a, s));
-                if (c->timing) c->timed_flops += conv_flops(Ly, px);
+                if (c->timing) c->timed_flops += conv_flops(L5, px);
             }
-            const Layer& L5 = c->layers[layer_id(c, b, r, 4)];
-            ConvArgs a = base_args(c, L5, N, h, w);
-            a.in = cur; a.in_stride = ct;
-            a.res1 = cur; a.res1_stride = ct; a.s1 = 0.2f;
-            if (r < 2) {
-                a.out = buf[r + 1];
-            } else {
-                a.out = buf[0];
-                a.res2 = buf[0]; a.res2_stride = ct; a.s2 = 0.2f;
-            }
-            a.out_stride = ct; a.out_coff = 0;
-            HIP_TRY(launch_conv(c, a, s));
-            if (c->timing) c->timed_flops += conv_flops(L5, px);
         }
     }
     if (c->timing) {
@@ -306,6 +336,7 @@ int nesr_create(nesr_ctx** out, int device_id, int conv_first_in_ch, int unshuff
     c->nout = num_out_ch;
     c->dtype = dtype;
     c->kgroup = dtype == NESR_DTYPE_BF16 ? 16 : 8;
+    if (const char* e = getenv("NESR_TRUNK")) c->trunk_mode = e[0] == 'l' ? 1 : (e[0] == 'p' ? 2 : 0);
     auto add = [&](const std::string& name, int cin, int cout) {
         Layer L;
         L.name = name;
@@ -403,6 +434,41 @@ int nesr_finalize_weights(nesr_ctx* c) {
         c->layers[i].d_w = c->d_weights + woff[i];
         c->layers[i].d_b = reinterpret_cast<float*>(c->d_weights + boff[i]);
     }
+    // layer table of the persistent trunk kernel (same wiring as the per-layer loop in run_forward)
+    {
+        std::vector<TrunkLayer> tl;
+        for (int b = 0; b < c->nb; ++b)
+            for (int r = 0; r < 3; ++r)
+                for (int k = 0; k < 5; ++k) {
+                    const Layer& Ly = c->layers[layer_id(c, b, r, k)];
+                    TrunkLayer t;
+                    std::memset(&t, 0, sizeof(t));
+                    t.in_buf = r;
+                    t.cin = Ly.cin_p;
+                    t.coutp = Ly.cout_p;
+                    t.w = Ly.d_w;
+                    t.bias = Ly.d_b;
+                    t.res1_buf = t.res2_buf = -1;
+                    t.s1 = t.s2 = 1.f;
+                    if (k < 4) {
+                        t.out_buf = r; t.out_coff = c->nf + k * c->gc; t.lrelu = 1;
+                    } else {
+                        t.out_coff = 0; t.lrelu = 0;
+                        t.res1_buf = r; t.s1 = 0.2f;
+                        if (r < 2) {
+                            t.out_buf = r + 1;
+                        } else {
+                            t.out_buf = 0; t.res2_buf = 0; t.s2 = 0.2f;
+                        }
+                    }
+                    tl.push_back(t);
+                }
+        if (c->d_trunk) { HIP_TRY(hipFree(c->d_trunk)); c->d_trunk = nullptr; }
+        if (!tl.empty()) {
+            HIP_TRY(hipMalloc((void**)&c->d_trunk, tl.size() * sizeof(TrunkLayer)));
+            HIP_TRY(hipMemcpy(c->d_trunk, tl.data(), tl.size() * sizeof(TrunkLayer), hipMemcpyHostToDevice));
+        }
+    }
     c->finalized = true;
     return NESR_OK;
 }
@@ -476,6 +542,18 @@ int nesr_kernel_time_ms(nesr_ctx* c, double* total_ms, int64_t* launches, double
     return NESR_OK;
 }
 
+int nesr_check_status(nesr_ctx* c) {
+    if (!c) return fail(NESR_ERR_ARG, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipDeviceSynchronize());
+    if (c->last_sync) {
+        unsigned flag = 0;
+        HIP_TRY(hipMemcpy(&flag, c->last_sync, 4, hipMemcpyDeviceToHost));
+        if (flag) return fail(NESR_ERR_HIP, "persistent trunk kernel aborted: a neighbour wait timed out (workgroups not co-resident?)");
+    }
+    return NESR_OK;
+}
+
 void nesr_destroy(nesr_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -484,6 +562,7 @@ void nesr_destroy(nesr_ctx* c) {
     for (auto& pr : c->ev_free) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (c->ws) (void)hipFree(c->ws);
     if (c->d_weights) (void)hipFree(c->d_weights);
+    if (c->d_trunk) (void)hipFree(c->d_trunk);
     delete c;
 }
 

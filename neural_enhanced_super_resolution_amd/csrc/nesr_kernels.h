@@ -54,6 +54,30 @@ hipError_t launch_conv3x3_bf16_big(const ConvArgs& a, hipStream_t s);   // conv3
 size_t packed_weight_elems_bf16(int cin_p, int coutp);
 void pack_weights_bf16(const float* oihw, int cout, int cin, int cin_p, int coutp, uint16_t* dst);
 
+// Persistent trunk (conv3x3_mfma.hip): all dense-block convs of the 23 RRDBs in ONE cooperative
+// launch.  Workgroups keep their tiles from layer to layer and synchronise with their 8
+// neighbouring tiles only (per-tile progress counters, agent-scope release/acquire), instead of 345
+// kernel boundaries at which the whole chip drains and refills.
+struct TrunkLayer {
+    int in_buf, out_buf, res1_buf, res2_buf;   // 0..2 = the rotating 192-channel buffers P,Q,R; -1 = none
+    int cin, coutp, out_coff, lrelu;
+    float s1, s2;
+    const void* w;
+    const float* bias;
+};
+struct TrunkArgs {
+    const TrunkLayer* layers;   // device array
+    int nlayers;
+    void* buf[3];
+    int stride;                 // channels per pixel of P,Q,R (192)
+    int n, h, w;
+    unsigned* progress;         // [tiles] layers completed per tile, zeroed before the launch
+    unsigned* abort_flag;       // set by a workgroup whose bounded wait timed out
+    const void* zeros;
+};
+// returns the workgroup count it would launch (0 = the persistent form does not apply)
+hipError_t launch_trunk_persist(const TrunkArgs& t, bool bf16, hipStream_t s);
+
 // input packers (pack.hip): NCHW f32 (+ pixel_unshuffle) -> NHWC with `cp` channels (zero padded)
 struct PackArgs {
     const void* src;     // f32 NCHW [n][c][hin][win]   or u8 HWC [hin][win][3] (n == 1)

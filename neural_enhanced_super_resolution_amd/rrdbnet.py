@@ -244,6 +244,11 @@ class RRDBNet(nn.Module):
         ctx = self._context(torch.device(device))
         _lib.check(_lib.load().nesr_set_kernel_timing(ctx, 1 if enable else 0), "nesr_set_kernel_timing")
 
+    def check_status(self):
+        """Synchronises the device and raises if asynchronous work of this model failed."""
+        if self._ctx is not None:
+            _lib.check(_lib.load().nesr_check_status(self._ctx[0]), "nesr_check_status")
+
     def kernel_time(self):
         """(total ms, launches, algorithmic flops) of the dense-block convs since the last call."""
         if self._ctx is None:
