@@ -95,6 +95,11 @@ size_t nesr_workspace_bytes(const nesr_ctx* ctx, int N, int H, int W);
 /* Pre-allocates the workspace (forward() grows it on demand otherwise, which synchronises). */
 int nesr_reserve(nesr_ctx* ctx, int N, int H, int W);
 
+/* Batch size <= max_batch (frames of H x W input evaluated by one forward()) whose trunk launches
+ * fill the device's compute units most evenly -- used by RealESRGANer.tile_process to group the
+ * equal-shaped tiles of upstream's tile grid. */
+int nesr_preferred_batch(const nesr_ctx* ctx, int H, int W, int max_batch);
+
 /* Algorithmic FLOPs (2 x MACs) of one forward() on N frames of H x W input. */
 double nesr_forward_flops(const nesr_ctx* ctx, int N, int H, int W);
 

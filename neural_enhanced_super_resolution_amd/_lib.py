@@ -27,6 +27,7 @@ SIGNATURES = {
     "nesr_forward_u8": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p]),
     "nesr_workspace_bytes": (_c.c_size_t, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int]),
     "nesr_reserve": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int]),
+    "nesr_preferred_batch": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int]),
     "nesr_forward_flops": (_c.c_double, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int]),
     "nesr_set_kernel_timing": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "nesr_kernel_time_ms": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_double)]),

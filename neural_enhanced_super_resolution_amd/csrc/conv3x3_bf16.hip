@@ -1,22 +1,35 @@
-// bf16 3x3 convolution, large-tile variant: the throughput kernel for 4K-class frames
+// bf16 3x3 convolution, large-tile ("XL") variant: the throughput kernel for 4K-class frames
 // (BASELINE.json configs[2], [3]).  v_mfma_f32_32x32x16_bf16 runs 16x the f32 MFMA rate, so the
-// f32 kernel's tiling (128 pixels per workgroup) is staging-bound in bf16; this kernel raises the
-// MFMA work per staged byte 4x and reuses each pixel fragment across the three vertical taps.
+// generic kernel's tiling (128 pixels per workgroup, register staging) is far from feeding it.
 //
-//   workgroup : 256 threads = 4 waves, output tile 16 rows x 32 cols (512 px) x all Cout (32|64)
-//   wave      : 4 output rows x 32 cols x NT 32-wide channel tiles -> 4*NT accumulators (f32x16)
-//   K loop    : 16-channel (32-byte) chunks.  The (16+2)x(32+2) halo tile and the 9x16xCout weight
-//               slab are copied global -> LDS by LDS-DMA (global_load_lds_dwordx4: per-lane source,
-//               lane-linear destination, no staging registers), 2 stages, one barrier per chunk.
-//               Out-of-image pixels (the conv's zero padding) read a device zero page.
+//   layout    : activations are channel-blocked, [C/16][pixels][16 bf16] (nesr_kernels.h, Map): one
+//               K-chunk (16 channels = 32 bytes) of neighbouring pixels is contiguous in HBM, so one
+//               LDS-DMA wave-instruction (64 lanes x 16 B) copies 32 pixels = 8 whole 128-byte
+//               lines.  (With NHWC every lane touched its own line and the kernels were bound by the
+//               L1's access rate at ~20 % of the MFMA peak: profiles/r01/bf16_tcp_bound.txt.)
+//   workgroup : 512 threads = 8 waves, output tile 32 x 32 pixels x all Cout (32|64), 1 per CU
+//   wave      : 4 output rows x 32 cols x NT 32-wide channel tiles -> 4*NT f32x16 accumulators
+//   K loop    : 16-channel chunks; the (32+2)x(32+2) halo tile and the 9x16xCout weight slab are
+//               copied global -> LDS by LDS-DMA (global_load_lds_dwordx4 from inline asm: per-lane
+//               source, lane-linear destination, no staging registers).  3-slot input ring (two
+//               chunks ahead: HBM / Infinity-Cache latency) + 2-slot weight ring (one chunk ahead:
+//               L2 latency), a COUNTED s_waitcnt vmcnt and a raw s_barrier: one barrier per chunk,
+//               the DMA never drains inside the loop.  Out-of-image pixels read a zero page.
+//                 iteration c:  s_waitcnt vmcnt(nin)  -> this wave's w(c), in(c) have landed
+//                               s_barrier             -> everyone's have; all finished compute(c-1)
+//                               issue w(c+1), in(c+2) into the slots last read in iteration c-1
+//                               compute(c)
+//   LDS image : input slot = [padded pixel][32 B]; the two 16-byte halves of pixel p are swapped
+//               when bit 3 of p is set (applied on the DMA source address and on the read), which
+//               makes the 16-lane ds_read_b128 groups conflict-free.
 //   operands  : for one horizontal tap dx the wave reads 6 pixel fragments (rows -1..4) once and
-//               uses each for up to 3 vertical taps: 6 + 3*NT ds_read_b128 per 12*NT MFMAs.
-//   schedule  : step (dx,dy) = 4*NT MFMAs; the weight fragments of the next step and the pixel
-//               fragments of the next dx are read during the current step (sched_barrier-pinned).
-//   placement : blockIdx -> tile through the bijective XCD remap, so each XCD's L2 serves a
-//               contiguous run of tiles (shared halo columns/rows and the weights hit L2).
-//   epilogue  : as the generic kernel (conv3x3_mfma.hip): weights are the MFMA A operand, pixels
-//               the B operand; every lane owns runs of 4 consecutive channels of one pixel per row.
+//               uses each for up to 3 vertical taps: 6 + 3*NT ds_read_b128 per 12*NT MFMAs; the next
+//               step's fragments are read during the current step's MFMAs (sched_barrier-pinned).
+//   placement : blockIdx -> tile through the bijective XCD remap (neighbouring tiles share an L2).
+//   epilogue  : weights are the MFMA A operand, pixels the B operand -> a lane owns runs of 4
+//               consecutive channels of one pixel; pairs of runs are exchanged between the two
+//               half-waves (v_permlane32_swap) so every lane stores 16 contiguous bytes and a wave
+//               instruction writes 1 KiB of whole lines.
 #include <hip/hip_bf16.h>
 
 #include "nesr_kernels.h"
@@ -30,38 +43,49 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int TH = 16, TW = 32;
-constexpr int PH = TH + 2, PW = TW + 2;
-constexpr int NPIX = PH * PW;          // 612
-constexpr int IN_ITEMS = 1280;         // 2 planes x 612 = 1224 16-byte items, padded to 5 rounds of 256
-constexpr int IN_ROUNDS = IN_ITEMS / 256;
-
-template <int NT>
-struct Geo {
-    static constexpr int W_ITEMS = 9 * 2 * 32 * NT;
-    static constexpr int ROUNDS = (IN_ITEMS + W_ITEMS + 255) / 256;
-    static constexpr int STAGE_ITEMS = ROUNDS * 256;
-    static constexpr int W_ROUNDS = ROUNDS - IN_ROUNDS;
-};
+constexpr int TH = 32, TW = 32, PH = 34, PW = 34;
+constexpr int NPIX = PH * PW;                       // 1156 padded pixels
+constexpr int IN_ITEMS = 2 * NPIX;                  // 2312 16-byte items per input slot
+constexpr int IN_ROUNDS = (IN_ITEMS + 511) / 512;   // 5 DMA rounds of 512 lanes
+constexpr int IN_BYTES = IN_ITEMS * 16;             // 36992
 
 typedef __attribute__((address_space(3))) char lds_char;
-typedef const __attribute__((address_space(1))) void* gptr_t;
 
 __device__ inline f32x4 ld4_bf16(const uint16_t* p) {
     const uint2 u = *reinterpret_cast<const uint2*>(p);
     return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
                  __uint_as_float(u.y & 0xffff0000u)};
 }
-__device__ inline void st4_bf16(uint16_t* p, f32x4 v) {
+__device__ inline uint2 pack4_bf16(f32x4 v) {   // plain casts -> v_cvt_pk_bf16_f32 (RNE, NaN preserving)
     const bf16x4 b = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-    *reinterpret_cast<uint2*>(p) = __builtin_bit_cast(uint2, b);
+    return __builtin_bit_cast(uint2, b);
+}
+
+// LDS-DMA from inline asm: hipcc does not count it, so it inserts no s_waitcnt vmcnt(0) before the
+// ds_reads of OTHER ring slots (with the builtin it cannot prove the slots do not alias and drains
+// the pipeline every chunk).  All waits for these DMAs are the hand-counted ones in the K loop.
+// M0 (LDS destination base) is compiler-reserved: saved and restored inside the statement
+// (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void glds16_asm(const char* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
 }
 
 template <int NT>
-__global__ __launch_bounds__(256, 2) void conv3x3_bf16_big_kernel(ConvArgs a) {
-    typedef Geo<NT> G;
+__global__ __launch_bounds__(512, 2) void conv3x3_bf16_xl_kernel(ConvArgs a) {
+    constexpr int W_ITEMS = 9 * 2 * 32 * NT;
+    constexpr int W_ROUNDS = (W_ITEMS + 511) / 512;
+    constexpr int W_BYTES = W_ITEMS * 16;
+    constexpr int WRING = 3 * IN_BYTES;   // LDS: [input ring: 3 x IN_BYTES][weight ring: 2 x W_BYTES]
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const f32x4* lds = reinterpret_cast<const f32x4*>(smem);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -81,47 +105,66 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_big_kernel(ConvArgs a) {
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;
 
-    // ---- LDS-DMA sources.  Item k of the input region = plane (k / 612), padded-tile pixel (k % 612).
+    // ---- LDS-DMA sources.  LDS item k of an input slot = padded pixel k>>1, 16-byte slot k&1; it
+    // holds channel half (k&1) ^ bit3(pixel) of that pixel's chunk.
     const char* zero_page = static_cast<const char*>(a.zeros);
     const char* isrc[IN_ROUNDS];
-    unsigned live = 0;   // bit i: round i's source advances 32 bytes per chunk (real pixel)
+    unsigned live = 0, present = 0;
     {
         const char* in = static_cast<const char*>(a.in);
 #pragma unroll
         for (int i = 0; i < IN_ROUNDS; ++i) {
-            const int k = tid + 256 * i;
-            const int half = k >= NPIX ? 1 : 0;
-            const int p = k - half * NPIX;
+            const int k = tid + 512 * i;
+            const int p = k >> 1;
+            const int half = (k & 1) ^ ((p >> 3) & 1);
             const int py = p / PW, px = p - py * PW;
             const int Y = y0 - 1 + py, X = x0 - 1 + px;
-            const bool ok = (k < 2 * NPIX) && Y >= 0 && Y < a.h && X >= 0 && X < a.w_;
+            const bool has = k < IN_ITEMS;
+            const bool ok = has && Y >= 0 && Y < a.h && X >= 0 && X < a.w_;
             const int sy = ok ? (Y >> a.up) : 0, sx = ok ? (X >> a.up) : 0;
-            isrc[i] = ok ? in + ((((size_t)n * a.in_h + sy) * a.in_w + sx) * a.in_stride) * 2 + half * 16 : zero_page;
+            isrc[i] = ok ? in + ((((size_t)n * a.in_h + sy) * a.in_w + sx) * a.in_map.pix) * 2 + half * 16 : zero_page;
             live |= ok ? (1u << i) : 0u;
+            present |= has ? (1u << i) : 0u;
         }
     }
+    const long long in_cstride = a.in_map.chunk * 2;   // bytes between K-chunks
     const char* wbase = static_cast<const char*>(a.w);
 
-    auto stage = [&](int c, int buf) {
-        lds_char* dst = (lds_char*)(smem) + (size_t)buf * (G::STAGE_ITEMS * 16) + wave * 1024;
+    // LDS-DMA is EXEC-masked: lanes without an item do not write, so the rings need no padding.
+    // vmcnt counts WAVE instructions, so the number of DMA instructions a wave issues per call
+    // must be known exactly: rounds in which the wave has no item at all are skipped by a
+    // wave-uniform (scalar) branch, partial waves run the instruction with partial EXEC.
+    const unsigned lds_base = (unsigned)(size_t)(lds_char*)(smem);
+    const int nin = (IN_ITEMS - wave * 64 + 511) / 512;   // input DMA instructions of this wave per chunk (4 or 5)
+    const int nwt = (W_ITEMS - wave * 64 + 511) / 512;
+    auto issue_in = [&](int c, int slot) {
+        const unsigned dst = lds_base + slot * IN_BYTES + wave * 1024;
 #pragma unroll
         for (int i = 0; i < IN_ROUNDS; ++i) {
-            const char* s = isrc[i] + (((live >> i) & 1u) ? c * 32 : 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)s, dst + i * 4096, 16, 0, 0);
+            if (i < nin) {
+                const char* s = isrc[i] + (((live >> i) & 1u) ? (long long)c * in_cstride : 0ll);
+                if ((present >> i) & 1u) glds16_asm(s, __builtin_amdgcn_readfirstlane(dst + i * 8192));
+            }
         }
-        const char* wc = wbase + (size_t)c * (G::W_ITEMS * 16);
+    };
+    auto issue_w = [&](int c, int slot) {
+        const unsigned dst = lds_base + WRING + slot * W_BYTES + wave * 1024;
+        const char* wc = wbase + (size_t)c * W_BYTES;
 #pragma unroll
-        for (int i = 0; i < G::W_ROUNDS; ++i) {
-            const int k = tid + 256 * i;
-            const char* s = k < G::W_ITEMS ? wc + k * 16 : zero_page;
-            __builtin_amdgcn_global_load_lds((gptr_t)s, dst + (IN_ROUNDS + i) * 4096, 16, 0, 0);
+        for (int i = 0; i < W_ROUNDS; ++i) {
+            if (i < nwt) {
+                const int k = tid + 512 * i;
+                if (k < W_ITEMS) glds16_asm(wc + k * 16, __builtin_amdgcn_readfirstlane(dst + i * 8192));
+            }
         }
     };
 
     // ---- per-lane operand coordinates
     const int m = lane & 31, hh = lane >> 5;
-    const int p_base = hh * NPIX + (4 * wave) * PW + m;           // + r*PW + dx
-    const int w_base = IN_ITEMS + hh * (32 * NT) + m;             // + tap*2*(32*NT) + t*32
+    const int p_row0 = (4 * wave) * PW + m;           // padded pixel of (row 0 of this wave's 6, col m, dx 0)
+    const int w_off = hh * (32 * NT) + m;             // item index inside a weight slot
+    // waves whose 4 rows are all below the image do no arithmetic (edge tiles), but still stage and barrier
+    const bool active = (y0 + 4 * wave) < a.h;
 
     f32x16 acc[4][NT];
 #pragma unroll
@@ -132,43 +175,65 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_big_kernel(ConvArgs a) {
             for (int e = 0; e < 16; ++e) acc[r][t][e] = 0.f;
 
     const int nchunks = a.cin / 16;
-    stage(0, 0);
-    __syncthreads();   // vmcnt(0) + barrier: chunk 0 landed
+    // prologue: in(0), w(0), in(1) -- the loop's first wait leaves exactly in(1) in flight
+    issue_in(0, 0);
+    issue_w(0, 0);
+    if (nchunks > 1) issue_in(1, 1);
+    int islot = 0, ifill = 2;
     for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) stage(c + 1, (c + 1) & 1);
-        const f32x4* st = lds + (c & 1) * G::STAGE_ITEMS;
-        f32x4 P[2][6];
-        f32x4 Wf[2][NT];
+        // all of this wave's DMAs except in(c+1) (its nin newest instructions) must have landed
+        if (c + 1 >= nchunks)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (nin == IN_ROUNDS)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_ROUNDS) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_ROUNDS - 1) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (c + 1 < nchunks) issue_w(c + 1, (c + 1) & 1);
+        if (c + 2 < nchunks) issue_in(c + 2, ifill);
+        if (active) {
+            const char* st = smem + islot * IN_BYTES;
+            const f32x4* sw = reinterpret_cast<const f32x4*>(smem + WRING + (c & 1) * W_BYTES);
+            auto pix_frag = [&](int r, int dx) -> f32x4 {
+                const int p = p_row0 + r * PW + dx;
+                return *reinterpret_cast<const f32x4*>(st + p * 32 + ((hh ^ ((p >> 3) & 1)) << 4));
+            };
+            f32x4 P[2][6];
+            f32x4 Wf[2][NT];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) P[0][r] = st[p_base + r * PW];
+            for (int r = 0; r < 6; ++r) P[0][r] = pix_frag(r, 0);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) Wf[0][t] = st[w_base + t * 32];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 9; ++s) {
-            const int dx = s / 3, dy = s - dx * 3;
-            if (s + 1 < 9) {
-                const int dx1 = (s + 1) / 3, dy1 = (s + 1) - dx1 * 3;
-                const int tap1 = dy1 * 3 + dx1;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) Wf[(s + 1) & 1][t] = st[w_base + tap1 * 2 * (32 * NT) + t * 32];
-            }
-            if (dy == 0 && dx < 2) {
-#pragma unroll
-                for (int r = 0; r < 6; ++r) P[(dx + 1) & 1][r] = st[p_base + r * PW + dx + 1];
-            }
+            for (int t = 0; t < NT; ++t) Wf[0][t] = sw[w_off + t * 32];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int s = 0; s < 9; ++s) {
+                const int dx = s / 3, dy = s - dx * 3;
+                if (s + 1 < 9) {
+                    const int dx1 = (s + 1) / 3, dy1 = (s + 1) - dx1 * 3;
+                    const int tap1 = dy1 * 3 + dx1;
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Wf[s & 1][t]),
-                                                                        __builtin_bit_cast(bf16x8, P[dx & 1][r + dy]),
-                                                                        acc[r][t], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                    for (int t = 0; t < NT; ++t) Wf[(s + 1) & 1][t] = sw[w_off + tap1 * 2 * (32 * NT) + t * 32];
+                }
+                if (dy == 0 && dx < 2) {
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) P[(dx + 1) & 1][r] = pix_frag(r, dx + 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Wf[s & 1][t]),
+                                                                            __builtin_bit_cast(bf16x8, P[dx & 1][r + dy]),
+                                                                            acc[r][t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        __syncthreads();   // next chunk landed (vmcnt(0)) and every wave is done with this stage
+        islot = islot == 2 ? 0 : islot + 1;
+        ifill = ifill == 2 ? 0 : ifill + 1;
     }
+    if (!active) return;
 
     // ---- epilogue: lane = pixel column m of rows 4*wave + r; regs = 4-channel runs 8g + 4hh (+32t)
     const int X = x0 + m;
@@ -188,18 +253,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_big_kernel(ConvArgs a) {
         const int Y = y0 + 4 * wave + r;
         const bool valid = xok && Y < a.h;
         const size_t pix = ((size_t)n * a.h + (Y < a.h ? Y : 0)) * a.w_ + Xc;
+        auto at = [&](const Map& mp, int c) -> size_t { return (size_t)(c >> 4) * mp.chunk + pix * mp.pix + (c & 15); };
         f32x4 r1[NT][4], r2[NT][4];
         if (res1) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) r1[t][g] = ld4_bf16(res1 + pix * a.res1_stride + t * 32 + 8 * g + 4 * hh);
+                for (int g = 0; g < 4; ++g) r1[t][g] = ld4_bf16(res1 + at(a.res1_map, t * 32 + 8 * g + 4 * hh));
         }
         if (res2) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) r2[t][g] = ld4_bf16(res2 + pix * a.res2_stride + t * 32 + 8 * g + 4 * hh);
+                for (int g = 0; g < 4; ++g) r2[t][g] = ld4_bf16(res2 + at(a.res2_map, t * 32 + 8 * g + 4 * hh));
         }
         f32x4 v[NT][4];
 #pragma unroll
@@ -214,18 +280,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_big_kernel(ConvArgs a) {
                     if (res2) x = __fadd_rn(__fmul_rn(x, a.s2), r2[t][g][q]);
                     v[t][g][q] = x;
                 }
+        // 16-byte stores: for the run pair (g = 2j, 2j+1) the lower half-wave ends up with channels
+        // 16j..16j+7 of its pixel (own run 2j + the upper lane's run 2j) and the upper half-wave with
+        // 16j+8..16j+15 (the lower lane's run 2j+1 + own run 2j+1).  permlane32_swap(x, y): lanes 32-63
+        // of x <-> lanes 0-31 of y.  All lanes execute the swaps (no divergence before them).
+        uint4 wide[NT][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint2 e = pack4_bf16(v[t][2 * j]), o = pack4_bf16(v[t][2 * j + 1]);
+                const auto sx = __builtin_amdgcn_permlane32_swap(e.x, o.x, false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(e.y, o.y, false, false);
+                wide[t][j] = uint4{sx[0], sy[0], sx[1], sy[1]};
+            }
         if (valid) {
+            // lane (pixel, hh) stores channels t*32 + 16j + 8hh .. +7
             if (out) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) st4_bf16(out + pix * a.out_stride + a.out_coff + t * 32 + 8 * g + 4 * hh, v[t][g]);
+                    for (int j = 0; j < 2; ++j)
+                        *reinterpret_cast<uint4*>(out + at(a.out_map, a.out_coff + t * 32 + 16 * j + 8 * hh)) = wide[t][j];
             }
             if (out2) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) st4_bf16(out2 + pix * a.out2_stride + t * 32 + 8 * g + 4 * hh, v[t][g]);
+                    for (int j = 0; j < 2; ++j)
+                        *reinterpret_cast<uint4*>(out2 + at(a.out2_map, t * 32 + 16 * j + 8 * hh)) = wide[t][j];
             }
             if (a.cout_real > 0 && hh == 0) {
 #pragma unroll
@@ -246,27 +329,28 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16_big_kernel(ConvArgs a) {
 }
 
 template <int NT>
-hipError_t launch_big(const ConvArgs& a, hipStream_t s) {
-    typedef Geo<NT> G;
-    constexpr size_t shm = 2 * (size_t)G::STAGE_ITEMS * 16;
+hipError_t launch_xl(const ConvArgs& a, hipStream_t s) {
+    constexpr size_t shm = 3 * (size_t)IN_BYTES + 2 * (size_t)(9 * 2 * 32 * NT * 16);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_big_kernel<NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_xl_kernel<NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int tiles = ((a.w_ + TW - 1) / TW) * ((a.h + TH - 1) / TH) * a.n;
-    hipLaunchKernelGGL((conv3x3_bf16_big_kernel<NT>), dim3(tiles), dim3(256), shm, s, a);
+    hipLaunchKernelGGL((conv3x3_bf16_xl_kernel<NT>), dim3(tiles), dim3(512), shm, s, a);
     return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t launch_conv3x3_bf16_big(const ConvArgs& a, hipStream_t s) {
+hipError_t launch_conv3x3_bf16_xl(const ConvArgs& a, hipStream_t s) {
     if (a.cin % 16 || !a.zeros) return hipErrorInvalidValue;
-    if (a.coutp == 64) return launch_big<2>(a, s);
-    if (a.coutp == 32) return launch_big<1>(a, s);
+    // the 16-byte accesses of the pair image / wide stores need pixel strides of whole 8-channel groups
+    if (a.in_map.pix % 8 || (a.out && (a.out_map.pix % 8 || a.out_coff % 16))) return hipErrorInvalidValue;
+    if (a.coutp == 64) return launch_xl<2>(a, s);
+    if (a.coutp == 32) return launch_xl<1>(a, s);
     return hipErrorInvalidValue;
 }
 

@@ -90,7 +90,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int n, const 
     constexpr int TOTAL_F4 = STAGE_F4;
     constexpr int R = (TOTAL_F4 + 255) / 256;
     const char* src[R];
-    int cstride[R];
+    long long cstride[R];
     int slot[R];
     bool zero[R];
     {
@@ -109,14 +109,15 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int n, const 
                 const int Y = y0 - 1 + py, X = x0 - 1 + px;
                 const bool ok = Y >= 0 && Y < a.h && X >= 0 && X < a.w_;
                 const int sy = ok ? (Y >> a.up) : 0, sx = ok ? (X >> a.up) : 0;
-                src[i] = in + ((((size_t)n * a.in_h + sy) * a.in_w + sx) * a.in_stride) * ES + half * 16;
-                cstride[i] = 32;
+                src[i] = in + ((((size_t)n * a.in_h + sy) * a.in_w + sx) * a.in_map.pix) * ES + half * 16;
+                cstride[i] = -1;   // input item: advances by the map's K-group stride
                 zero[i] = !ok;
             } else {
                 src[i] = wsrc + (size_t)(k - IN_F4) * 16;
                 cstride[i] = W_F4 * 16;
                 zero[i] = false;
             }
+            if (cstride[i] < 0) cstride[i] = a.in_map.chunk * ES;
         }
     }
 
@@ -124,7 +125,7 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int n, const 
     auto load_chunk = [&](int c) {
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src[i] + (size_t)c * cstride[i]);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src[i] + (long long)c * cstride[i]);
             pv[i] = zero[i] ? f32x4{0.f, 0.f, 0.f, 0.f} : v;
         }
     };
@@ -221,19 +222,21 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int n, const 
     const bool valid = Y < a.h && X < a.w_;
     const size_t pix = ((size_t)n * a.h + (valid ? Y : 0)) * a.w_ + (valid ? X : 0);
     f32x4 r1[NT][4], r2[NT][4];
+    // element offset of the 4-channel run starting at channel c (c % 4 == 0) of this lane's pixel
+    auto at = [&](const Map& mp, int c) -> size_t { return (size_t)(c / KG) * mp.chunk + pix * mp.pix + (c % KG); };
     if (a.res1) {
-        const T* rp = static_cast<const T*>(a.res1) + pix * a.res1_stride + 4 * hh;
+        const T* rp = static_cast<const T*>(a.res1);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) r1[t][g] = Elem<BF>::ld4(rp + t * 32 + 8 * g);
+            for (int g = 0; g < 4; ++g) r1[t][g] = Elem<BF>::ld4(rp + at(a.res1_map, t * 32 + 8 * g + 4 * hh));
     }
     if (a.res2) {
-        const T* rp = static_cast<const T*>(a.res2) + pix * a.res2_stride + 4 * hh;
+        const T* rp = static_cast<const T*>(a.res2);
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) r2[t][g] = Elem<BF>::ld4(rp + t * 32 + 8 * g);
+            for (int g = 0; g < 4; ++g) r2[t][g] = Elem<BF>::ld4(rp + at(a.res2_map, t * 32 + 8 * g + 4 * hh));
     }
     f32x4 v[NT][4];
 #pragma unroll
@@ -265,18 +268,18 @@ __device__ __forceinline__ void conv_tile(const ConvArgs& a, const int n, const 
     }
     if (valid) {
         if (a.out) {
-            T* op = static_cast<T*>(a.out) + pix * a.out_stride + a.out_coff + 4 * hh;
+            T* op = static_cast<T*>(a.out);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) Elem<BF>::st4(op + t * 32 + 8 * g, v[t][g]);
+                for (int g = 0; g < 4; ++g) Elem<BF>::st4(op + at(a.out_map, a.out_coff + t * 32 + 8 * g + 4 * hh), v[t][g]);
         }
         if (a.out2) {
-            T* op = static_cast<T*>(a.out2) + pix * a.out2_stride + 4 * hh;
+            T* op = static_cast<T*>(a.out2);
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) Elem<BF>::st4(op + t * 32 + 8 * g, v[t][g]);
+                for (int g = 0; g < 4; ++g) Elem<BF>::st4(op + at(a.out2_map, t * 32 + 8 * g + 4 * hh), v[t][g]);
         }
         if (a.cout_real > 0 && hh == 0) {
             // conv_last: channels 0..cout_real-1 (<= 4) live in v[0][0] of the lower half-wave
@@ -366,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void trunk_persist_kernel(TrunkArgs t) {
         const TrunkLayer ly = t.layers[L];
         ConvArgs a;
         a.in = t.buf[ly.in_buf];
-        a.in_stride = t.stride;
+        a.in_map = t.map;
         a.in_h = t.h;
         a.in_w = t.w;
         a.up = 0;
@@ -378,16 +381,16 @@ __global__ __launch_bounds__(256, 2) void trunk_persist_kernel(TrunkArgs t) {
         a.h = t.h;
         a.w_ = t.w;
         a.out = t.buf[ly.out_buf];
-        a.out_stride = t.stride;
+        a.out_map = t.map;
         a.out_coff = ly.out_coff;
         a.out2 = nullptr;
-        a.out2_stride = 0;
+        a.out2_map = t.map;
         a.lrelu = ly.lrelu;
         a.res1 = ly.res1_buf >= 0 ? t.buf[ly.res1_buf] : nullptr;
-        a.res1_stride = t.stride;
+        a.res1_map = t.map;
         a.s1 = ly.s1;
         a.res2 = ly.res2_buf >= 0 ? t.buf[ly.res2_buf] : nullptr;
-        a.res2_stride = t.stride;
+        a.res2_map = t.map;
         a.s2 = ly.s2;
         a.out_nchw = nullptr;
         a.cout_real = 0;
@@ -519,17 +522,20 @@ hipError_t launch_conv3x3_f32(const ConvArgs& a, hipStream_t s) { return launch<
 hipError_t launch_trunk_persist(const TrunkArgs& t, bool bf16, hipStream_t s) {
     return bf16 ? launch_trunk<true>(t, s) : launch_trunk<false>(t, s);
 }
-// bf16: frames of at least 128x128 trunk pixels take the large-tile LDS-DMA kernel; the choice
+// bf16: frames of more than 256x256 trunk pixels take the large-tile LDS-DMA kernel (a single
+// 256x256 frame is only 64 of its tiles, too few for 256 CUs); the choice
 // depends on the frame size only (never on the batch), so a tile's arithmetic is the same on every
-// rank and in every batch.  NESR_BF16_KERNEL=small|big overrides (tests, A/B timing).
+// rank and in every batch.  NESR_BF16_KERNEL=small|big|xl overrides (tests, A/B timing).
 hipError_t launch_conv3x3_bf16(const ConvArgs& a, hipStream_t s) {
     static const int mode = [] {
         const char* e = getenv("NESR_BF16_KERNEL");
         if (!e) return 0;
-        return e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : 0);
+        return e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : (e[0] == 'x' ? 3 : 0));
     }();
-    const bool big = mode == 2 || (mode == 0 && (long)a.h * a.w_ >= 128L * 128L);
-    if (big && a.zeros) return launch_conv3x3_bf16_big(a, s);
+    const bool large = (long)a.h * a.w_ > 256L * 256L;
+    if (a.zeros) {
+        if (mode == 3 || (mode == 0 && large)) return launch_conv3x3_bf16_xl(a, s);
+    }
     return launch<true>(a, s);
 }
 

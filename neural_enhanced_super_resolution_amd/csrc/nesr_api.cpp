@@ -147,6 +147,14 @@ ConvArgs base_args(const nesr_ctx* c, const Layer& L, int N, int h, int w) {
     return a;
 }
 
+// f32: NHWC (pix = channels of the buffer, chunk = 8).  bf16: channel-blocked [C/16][pixels][16].
+Map make_map(bool bf16, int channels, size_t pixels) {
+    Map m;
+    if (bf16) { m.pix = 16; m.chunk = (long long)pixels * 16; }
+    else { m.pix = channels; m.chunk = 8; }
+    return m;
+}
+
 double conv_flops(const Layer& L, double pixels) { return 2.0 * 9.0 * L.cin * L.cout * pixels; }
 
 // The forward graph.  x -> y; exactly one of (x_f32, x_u8) and one of (y_f32, y_u8) is set.
@@ -175,7 +183,11 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
     p.flip = flip;
     p.n = N; p.c = C; p.hin = H; p.win = W;
     p.unshuffle = u;
+    const size_t P1 = (size_t)N * h * w;
+    const Map m_in = make_map(bf, c->layers[0].cin_p, P1), m_f = make_map(bf, nf, P1), m_t = make_map(bf, ct, P1);
+    const Map m_u1 = make_map(bf, nf, P1 * 4), m_u2 = make_map(bf, nf, P1 * 16);
     p.dst = ws + L.in;
+    p.dst_map = m_in;
     p.cp = c->layers[0].cin_p;
     p.bf16 = bf;
     HIP_TRY(launch_pack_input(p, s));
@@ -183,9 +195,9 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
     // conv_first: IN -> A.x0 and F (feat is needed again after the trunk)
     {
         ConvArgs a = base_args(c, c->layers[0], N, h, w);
-        a.in = ws + L.in; a.in_stride = c->layers[0].cin_p;
-        a.out = ws + L.a; a.out_stride = ct; a.out_coff = 0;
-        a.out2 = ws + L.f; a.out2_stride = nf;
+        a.in = ws + L.in; a.in_map = m_in;
+        a.out = ws + L.a; a.out_map = m_t; a.out_coff = 0;
+        a.out2 = ws + L.f; a.out2_map = m_f;
         HIP_TRY(launch_conv(c, a, s));
     }
 
@@ -215,7 +227,7 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
         t.layers = c->d_trunk;
         t.nlayers = c->nb * 15;
         t.buf[0] = buf[0]; t.buf[1] = buf[1]; t.buf[2] = buf[2];
-        t.stride = ct;
+        t.map = m_t;
         t.n = N; t.h = h; t.w = w;
         t.progress = sync + 64;
         t.abort_flag = sync;
@@ -231,23 +243,23 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
                 for (int k = 0; k < 4; ++k) {
                     const Layer& Ly = c->layers[layer_id(c, b, r, k)];
                     ConvArgs a = base_args(c, Ly, N, h, w);
-                    a.in = cur; a.in_stride = ct;
-                    a.out = cur; a.out_stride = ct; a.out_coff = nf + k * gc;
+                    a.in = cur; a.in_map = m_t;
+                    a.out = cur; a.out_map = m_t; a.out_coff = nf + k * gc;
                     a.lrelu = 1;
                     HIP_TRY(launch_conv(c, a, s));
                     if (c->timing) c->timed_flops += conv_flops(Ly, px);
                 }
                 const Layer& L5 = c->layers[layer_id(c, b, r, 4)];
                 ConvArgs a = base_args(c, L5, N, h, w);
-                a.in = cur; a.in_stride = ct;
-                a.res1 = cur; a.res1_stride = ct; a.s1 = 0.2f;
+                a.in = cur; a.in_map = m_t;
+                a.res1 = cur; a.res1_map = m_t; a.s1 = 0.2f;
                 if (r < 2) {
                     a.out = buf[r + 1];
                 } else {
                     a.out = buf[0];
-                    a.res2 = buf[0]; a.res2_stride = ct; a.s2 = 0.2f;
+                    a.res2 = buf[0]; a.res2_map = m_t; a.s2 = 0.2f;
                 }
-                a.out_stride = ct; a.out_coff = 0;
+                a.out_map = m_t; a.out_coff = 0;
                 HIP_TRY(launch_conv(c, a, s));
                 if (c->timing) c->timed_flops += conv_flops(L5, px);
             }
@@ -263,36 +275,36 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
     // feat = feat + conv_body(trunk)   (in place on F)
     {
         ConvArgs a = base_args(c, c->layers[tail], N, h, w);
-        a.in = buf[0]; a.in_stride = ct;
-        a.out = ws + L.f; a.out_stride = nf;
-        a.res1 = ws + L.f; a.res1_stride = nf; a.s1 = 1.0f;
+        a.in = buf[0]; a.in_map = m_t;
+        a.out = ws + L.f; a.out_map = m_f;
+        a.res1 = ws + L.f; a.res1_map = m_f; a.s1 = 1.0f;
         HIP_TRY(launch_conv(c, a, s));
     }
     // lrelu(conv_up1(nearest2x(feat)))
     {
         ConvArgs a = base_args(c, c->layers[tail + 1], N, 2 * h, 2 * w);
-        a.in = ws + L.f; a.in_stride = nf; a.in_h = h; a.in_w = w; a.up = 1;
-        a.out = ws + L.u1; a.out_stride = nf; a.lrelu = 1;
+        a.in = ws + L.f; a.in_map = m_f; a.in_h = h; a.in_w = w; a.up = 1;
+        a.out = ws + L.u1; a.out_map = m_u1; a.lrelu = 1;
         HIP_TRY(launch_conv(c, a, s));
     }
     // lrelu(conv_up2(nearest2x(feat)))
     {
         ConvArgs a = base_args(c, c->layers[tail + 2], N, 4 * h, 4 * w);
-        a.in = ws + L.u1; a.in_stride = nf; a.in_h = 2 * h; a.in_w = 2 * w; a.up = 1;
-        a.out = ws + L.u2; a.out_stride = nf; a.lrelu = 1;
+        a.in = ws + L.u1; a.in_map = m_u1; a.in_h = 2 * h; a.in_w = 2 * w; a.up = 1;
+        a.out = ws + L.u2; a.out_map = m_u2; a.lrelu = 1;
         HIP_TRY(launch_conv(c, a, s));
     }
     // lrelu(conv_hr(feat))
     {
         ConvArgs a = base_args(c, c->layers[tail + 3], N, 4 * h, 4 * w);
-        a.in = ws + L.u2; a.in_stride = nf;
-        a.out = ws + L.u3; a.out_stride = nf; a.lrelu = 1;
+        a.in = ws + L.u2; a.in_map = m_u2;
+        a.out = ws + L.u3; a.out_map = m_u2; a.lrelu = 1;
         HIP_TRY(launch_conv(c, a, s));
     }
     // conv_last -> planar f32 NCHW, or clamped + quantised u8 HWC
     {
         ConvArgs a = base_args(c, c->layers[tail + 4], N, 4 * h, 4 * w);
-        a.in = ws + L.u3; a.in_stride = nf;
+        a.in = ws + L.u3; a.in_map = m_u2;
         a.cout_real = c->nout;
         a.out_nchw = y_f32;
         a.out_u8 = y_u8;
@@ -516,6 +528,29 @@ double nesr_forward_flops(const nesr_ctx* c, int N, int H, int W) {
     return f;
 }
 
+int nesr_preferred_batch(const nesr_ctx* c, int H, int W, int max_batch) {
+    if (!c || H <= 0 || W <= 0 || max_batch <= 1) return 1;
+    const int u = c->ufac();
+    const int h = (H + u - 1) / u, w = (W + u - 1) / u;
+    // workgroups per frame of the trunk convs (the kernel choice mirrors launch_conv3x3_bf16)
+    const bool xl = c->dtype == NESR_DTYPE_BF16 && (long)h * w > 256L * 256L;
+    const long per = xl ? (long)((h + 31) / 32) * ((w + 31) / 32) : (long)((h + 7) / 8) * ((w + 15) / 16);
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    const long slots = (long)cus * (xl ? 1 : 2);   // co-resident workgroups
+    auto eff = [&](int b) {
+        const long wgs = per * b;
+        return (double)wgs / (double)(((wgs + slots - 1) / slots) * slots);
+    };
+    double best_eff = 0.0;
+    for (int b = 1; b <= max_batch; ++b) best_eff = eff(b) > best_eff ? eff(b) : best_eff;
+    int best = 1;
+    for (int b = 1; b <= max_batch; ++b)
+        if (eff(b) >= best_eff - 0.02) best = b;   // the largest batch within 2 % of the best fill: fewest launches
+    return best;
+}
+
 int nesr_set_kernel_timing(nesr_ctx* c, int enable) {
     if (!c) return fail(NESR_ERR_ARG, "null ctx");
     c->timing = enable != 0;
@@ -599,18 +634,19 @@ int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, in
     HIP_TRY(hipMemcpy(d_b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
     PackArgs p;
     std::memset(&p, 0, sizeof(p));
-    p.src = x_dev; p.n = N; p.c = Cin; p.hin = H; p.win = W; p.unshuffle = 1; p.dst = d_in; p.cp = cin_p; p.bf16 = bf;
+    const Map mi = make_map(bf, cin_p, (size_t)N * H * W), mo = make_map(bf, cout_p, (size_t)N * ho * wo);
+    p.src = x_dev; p.n = N; p.c = Cin; p.hin = H; p.win = W; p.unshuffle = 1; p.dst = d_in; p.dst_map = mi; p.cp = cin_p; p.bf16 = bf;
     HIP_TRY(launch_pack_input(p, s));
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.in = d_in; a.in_stride = cin_p; a.in_h = H; a.in_w = W; a.up = up; a.cin = cin_p;
+    a.in = d_in; a.in_map = mi; a.in_h = H; a.in_w = W; a.up = up; a.cin = cin_p;
     a.w = d_w; a.bias = d_b; a.coutp = cout_p;
     a.n = N; a.h = ho; a.w_ = wo;
-    a.out = d_out; a.out_stride = cout_p; a.out_coff = 0;
+    a.out = d_out; a.out_map = mo; a.out_coff = 0;
     a.lrelu = lrelu ? 1 : 0; a.s1 = a.s2 = 1.f;
     a.zeros = d_zero;
     HIP_TRY(bf ? launch_conv3x3_bf16(a, s) : launch_conv3x3_f32(a, s));
-    HIP_TRY(launch_nhwc_to_nchw(d_out, bf, cout_p, N, Cout, ho, wo, static_cast<float*>(y_dev), s));
+    HIP_TRY(launch_nhwc_to_nchw(d_out, bf, mo, N, Cout, ho, wo, static_cast<float*>(y_dev), s));
     HIP_TRY(hipStreamSynchronize(s));
     (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_zero);
     return NESR_OK;

@@ -6,32 +6,46 @@
 
 namespace nesr {
 
-// One fused 3x3 / stride 1 / zero-pad 1 convolution over NHWC activations
-// (feature maps are NHWC; an RDB owns one 192-channel buffer whose channel
-// slices are x0|x1|x2|x3|x4, so torch.cat disappears).
+// Activation addressing.  Channels are grouped in K-groups of KG channels (8 for f32, 16 for
+// bf16 = 32 bytes, one MFMA K-chunk); element (pixel p, channel c) of a feature map lives at
+//     base + (c / KG) * chunk + p * pix + (c % KG)          (in elements)
+//   NHWC (f32 path)            : pix = C_total, chunk = KG      -> base + p*C + c
+//   channel-blocked (bf16 path): pix = KG,      chunk = P*KG    -> [C/KG][P pixels][KG]
+// The blocked form makes one K-chunk of neighbouring pixels contiguous in HBM, so the staging
+// loads / LDS-DMA read whole 128-byte lines (NHWC gives every lane its own line: the bf16 kernels
+// were L1-access-bound, profiles/r01/bf16_tcp_bound.txt).  SURVEY.md section 7's "one 192-channel
+// buffer whose channel slices are x0|x1|x2|x3|x4" holds in both forms: a slice is a channel range.
+struct Map {
+    int pix;          // elements between consecutive pixels
+    long long chunk;  // elements between consecutive K-groups
+};
+
+// One fused 3x3 / stride 1 / zero-pad 1 convolution (torch.cat-free dense block: conv k reads
+// channels [0, cin) and writes channels [out_coff, out_coff + coutp) of the same buffer).
 struct ConvArgs {
-    // input: NHWC, `in_stride` elements between pixels, channels [0, cin) are read.
+    // input: channels [0, cin) are read
     const void* in;
-    int in_stride;
+    Map in_map;
     int in_h, in_w;        // stored (source) height/width
     int up;                // 1: the logical input is the nearest x2 upsample of the stored one
                            //    (F.interpolate(scale_factor=2, mode='nearest') folded into addressing)
-    int cin;               // padded to a multiple of the kernel's K-group (8 for f32, 16 for bf16)
+    int cin;               // padded to a multiple of KG
     // packed weights / bias (device)
     const void* w;
     const float* bias;     // [coutp] f32
     int coutp;             // padded output channels: 32 or 64
     // geometry of the convolution (logical input == output spatial size)
     int n, h, w_;
-    // NHWC output (may be null when out_nchw / out_u8 is used)
+    // feature-map output (may be null when out_nchw / out_u8 is used)
     void* out;
-    int out_stride, out_coff;
+    Map out_map;
+    int out_coff;
     void* out2;            // optional second copy of the same values (channels [0,coutp))
-    int out2_stride;
+    Map out2_map;
     // epilogue: v = acc + bias; if lrelu v = leaky(v, 0.2); if res1 v = v*s1 + res1; if res2 v = v*s2 + res2
     int lrelu;
-    const void* res1; int res1_stride; float s1;
-    const void* res2; int res2_stride; float s2;
+    const void* res1; Map res1_map; float s1;
+    const void* res2; Map res2_map; float s2;
     // planar f32 output [n][cout_real][h][w] (conv_last feeding RRDBNet.forward's NCHW result)
     float* out_nchw;
     int cout_real;
@@ -50,7 +64,7 @@ void pack_weights_f32(const float* oihw, int cout, int cin, int cin_p, int coutp
 
 // bf16 path: v_mfma_f32_32x32x16_bf16 implicit GEMM (conv3x3_bf16.hip)
 hipError_t launch_conv3x3_bf16(const ConvArgs& a, hipStream_t s);       // picks the variant by frame size
-hipError_t launch_conv3x3_bf16_big(const ConvArgs& a, hipStream_t s);   // conv3x3_bf16.hip: 16x32-px tiles, LDS-DMA
+hipError_t launch_conv3x3_bf16_xl(const ConvArgs& a, hipStream_t s);    // conv3x3_bf16.hip: 32x32-px tiles, 3-deep LDS-DMA ring
 size_t packed_weight_elems_bf16(int cin_p, int coutp);
 void pack_weights_bf16(const float* oihw, int cout, int cin, int cin_p, int coutp, uint16_t* dst);
 
@@ -69,7 +83,7 @@ struct TrunkArgs {
     const TrunkLayer* layers;   // device array
     int nlayers;
     void* buf[3];
-    int stride;                 // channels per pixel of P,Q,R (192)
+    Map map;                    // addressing of P,Q,R (192 channels each)
     int n, h, w;
     unsigned* progress;         // [tiles] layers completed per tile, zeroed before the launch
     unsigned* abort_flag;       // set by a workgroup whose bounded wait timed out
@@ -85,13 +99,14 @@ struct PackArgs {
     int flip;
     int n, c, hin, win;
     int unshuffle;       // 1, 2 or 4
-    void* dst;           // NHWC [n][hin/u][win/u][cp]
+    void* dst;           // feature map with cp channels (zero padded), addressed through dst_map
+    Map dst_map;
     int cp;
-    int bf16;            // destination element type
+    int bf16;            // destination element type (KG = 16) else f32 (KG = 8)
 };
 hipError_t launch_pack_input(const PackArgs& a, hipStream_t s);
 
-// NHWC (stride, channels [0,c)) -> planar f32 NCHW; used by the single-layer test hook
-hipError_t launch_nhwc_to_nchw(const void* src, int bf16, int stride, int n, int c, int h, int w, float* dst, hipStream_t s);
+// feature map (channels [0,c)) -> planar f32 NCHW; used by the single-layer test hook
+hipError_t launch_nhwc_to_nchw(const void* src, int bf16, Map map, int n, int c, int h, int w, float* dst, hipStream_t s);
 
 }  // namespace nesr

@@ -43,15 +43,17 @@ __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
                     v = src[(((size_t)n * a.c + c) * a.hin + Y) * a.win + X];
                 }
             }
+            const int kg = a.bf16 ? 16 : 8;
+            const size_t idx = (size_t)(co / kg) * a.dst_map.chunk + pix * a.dst_map.pix + (co % kg);
             if (a.bf16)
-                static_cast<uint16_t*>(a.dst)[pix * a.cp + co] = f2bf(v);
+                static_cast<uint16_t*>(a.dst)[idx] = f2bf(v);
             else
-                static_cast<float*>(a.dst)[pix * a.cp + co] = v;
+                static_cast<float*>(a.dst)[idx] = v;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* src, int bf16, int stride, int n, int c, int h, int w, float* dst) {
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* src, int bf16, Map map, int n, int c, int h, int w, float* dst) {
     const size_t total = (size_t)n * c * h * w;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % w);
@@ -59,7 +61,9 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* src, int 
         const int ch = (int)((i / ((size_t)w * h)) % c);
         const int nn = (int)(i / ((size_t)w * h * c));
         const size_t pix = ((size_t)nn * h + y) * w + x;
-        dst[i] = bf16 ? bf2f(static_cast<const uint16_t*>(src)[pix * stride + ch]) : static_cast<const float*>(src)[pix * stride + ch];
+        const int kg = bf16 ? 16 : 8;
+        const size_t idx = (size_t)(ch / kg) * map.chunk + pix * map.pix + (ch % kg);
+        dst[i] = bf16 ? bf2f(static_cast<const uint16_t*>(src)[idx]) : static_cast<const float*>(src)[idx];
     }
 }
 
@@ -74,12 +78,12 @@ hipError_t launch_pack_input(const PackArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_nhwc_to_nchw(const void* src, int bf16, int stride, int n, int c, int h, int w, float* dst, hipStream_t s) {
+hipError_t launch_nhwc_to_nchw(const void* src, int bf16, Map map, int n, int c, int h, int w, float* dst, hipStream_t s) {
     const size_t total = (size_t)n * c * h * w;
     if (total == 0) return hipSuccess;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks), dim3(256), 0, s, src, bf16, stride, n, c, h, w, dst);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(blocks), dim3(256), 0, s, src, bf16, map, n, c, h, w, dst);
     return hipGetLastError();
 }
 

@@ -57,7 +57,7 @@ class RealESRGANer:
         self.pre_pad = pre_pad
         self.mod_scale = None
         self.half = half
-        self.tile_batch = 8   # equal-shaped tiles evaluated per forward call (1 = upstream's serial loop)
+        self.tile_batch = 24  # upper bound on equal-shaped tiles per forward call (1 = upstream's serial loop)
 
         if gpu_id:
             self.device = torch.device(f"cuda:{gpu_id}" if torch.cuda.is_available() else "cpu") if device is None else device
@@ -168,8 +168,12 @@ class RealESRGANer:
         for t in grid:
             (py0, py1, px0, px1) = t[0]
             groups.setdefault((py1 - py0, px1 - px0), []).append(t)
-        nb = max(1, int(self.tile_batch)) if batch == 1 else 1
-        for tiles in groups.values():
+        nb_max = max(1, int(self.tile_batch)) if batch == 1 else 1
+        for (th, tw), tiles in groups.items():
+            nb = nb_max
+            if nb > 1 and isinstance(self.model, RRDBNet) and self.img.device.type == "cuda":
+                # occupancy-aware grouping: a batch whose workgroup count is a multiple of the CU count
+                nb = self.model.preferred_batch(self.img.device, th, tw, min(nb_max, len(tiles)))
             for i in range(0, len(tiles), nb):
                 chunk = tiles[i:i + nb]
                 if len(chunk) == 1:

@@ -244,6 +244,11 @@ class RRDBNet(nn.Module):
         ctx = self._context(torch.device(device))
         _lib.check(_lib.load().nesr_set_kernel_timing(ctx, 1 if enable else 0), "nesr_set_kernel_timing")
 
+    def preferred_batch(self, device, h, w, max_batch):
+        """Tiles of h x w input per forward call that fill the GPU's CUs most evenly (<= max_batch)."""
+        ctx = self._context(torch.device(device))
+        return max(1, int(_lib.load().nesr_preferred_batch(ctx, h, w, max_batch)))
+
     def check_status(self):
         """Synchronises the device and raises if asynchronous work of this model failed."""
         if self._ctx is not None:

@@ -83,7 +83,7 @@ BIG = (136, 160)   # >= 128*128 trunk pixels: the bf16 path takes the large-tile
 
 
 @pytest.mark.parametrize("cin,cout", [(16, 64), (64, 32), (96, 32), (160, 32), (192, 64), (64, 64), (64, 3)])
-def test_conv3x3_bf16_big_tile_kernel(cuda_device, cin, cout):
+def test_conv3x3_bf16_xl_kernel(cuda_device, cin, cout):
     from neural_enhanced_super_resolution_amd import conv3x3
     x, w, b = _case(cin, cout, BIG[0], BIG[1], seed=3 * cin + cout, n=2)
     ref = F.leaky_relu(F.conv2d(x.bfloat16().float(), w.bfloat16().float(), b, padding=1), 0.2)
@@ -92,7 +92,7 @@ def test_conv3x3_bf16_big_tile_kernel(cuda_device, cin, cout):
     assert (got - ref).abs().max().item() < 2 ** -7 * scale
 
 
-def test_conv3x3_bf16_big_tile_one_hot_taps(cuda_device):
+def test_conv3x3_bf16_xl_one_hot_taps(cuda_device):
     """Exact one-hot check of the large-tile kernel's tap / row-reuse / channel bookkeeping
     (small integers are exact in bf16)."""
     from neural_enhanced_super_resolution_amd import conv3x3
@@ -109,7 +109,7 @@ def test_conv3x3_bf16_big_tile_one_hot_taps(cuda_device):
         assert torch.equal(got, ref), f"tap {tap}"
 
 
-def test_conv3x3_bf16_big_tile_upsample(cuda_device):
+def test_conv3x3_bf16_xl_upsample(cuda_device):
     from neural_enhanced_super_resolution_amd import conv3x3
     x, wgt, b = _case(64, 64, 70, 90, seed=8)
     ref = F.conv2d(F.interpolate(x.bfloat16().float(), scale_factor=2, mode="nearest"), wgt.bfloat16().float(), b, padding=1)
