@@ -59,6 +59,18 @@ def host_threads(cap=16):
     return max(1, min(n, cap))
 
 
+def pmc_traffic(workload):
+    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x 2 -- the gfx950 correction of MI355X_MICROARCH.md -- plus WRITE_SIZE); PMC counters
+    cannot be collected inside this process, so the figure comes from profiles/ (null if absent)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload)
+    except Exception:
+        return None
+
+
 def cpu_baseline(sd, frame, scale, crop, threads):
     """Times the oracle on a crop of the frame; returns (dict, oracle float output of the crop)."""
     import numpy as np
@@ -122,7 +134,17 @@ def main():
     up.pre_process(np.ascontiguousarray(frame[:, :, ::-1].astype(np.float32) / 255.0))
     x = up.img
 
+    sharded_frame = wl["tile"] > 0 and world > 1
+    if sharded_frame:
+        # one frame for the whole job: tiles of upstream's grid sharded over the ranks, overlap rows
+        # exchanged point-to-point over RCCL, result gathered on rank 0 (strong scaling)
+        from neural_enhanced_super_resolution_amd import sharded
+        frame = synthetic_frame(wl["h"], wl["w"], seed=0)
+        band = torch.from_numpy(sharded.scatter_rows(frame, rank, world)).to(dev)
+
     def step():
+        if sharded_frame:
+            return sharded.enhance_sharded(up, band, (wl["h"], wl["w"]))
         if wl["tile"] > 0:
             up.tile_process()
             return up.output
@@ -155,31 +177,37 @@ def main():
         elapsed = float(t.item())
 
     out_mp = wl["h"] * netscale * wl["w"] * netscale / 1e6
-    value = world * args.steps * out_mp / elapsed
+    frames_per_step = 1 if sharded_frame else world
+    value = frames_per_step * args.steps * out_mp / elapsed
     frame_flops = net.forward_flops(1, wl["h"], wl["w"])
 
     result = {
         "metric": "output megapixels/sec, RealESRGAN_x2plus x2 upscale" if scale == 2 else "output megapixels/sec, RealESRGAN_x4plus x4 upscale",
         "value": round(value, 3), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+        "scaling": "strong" if sharded_frame else "weak",
         "vs_baseline": None, "dtype": dtype, "data": "synthetic (seeded frames, seeded random-init weights)",
-        "config": {"workload": f"{args.workload}: {wl['desc']}", "frames_per_step_per_gpu": 1,
+        "config": {"workload": f"{args.workload}: {wl['desc']}",
+                   "frames_per_step": frames_per_step,
+                   "partition": ("tiles of the 512/10 grid sharded over ranks, RCCL p2p overlap rows, gather on rank 0" if sharded_frame
+                                 else "independent frames, no data-path collective"),
                    "boundary": "RRDBNet.forward on the device-resident NCHW f32 tensor of RealESRGANer.pre_process",
                    "tflop_per_frame": round(frame_flops / 1e12, 4)},
-        "frames_per_s": round(world * args.steps / elapsed, 4),
-        "tflops_whole_net": round(world * args.steps * frame_flops / elapsed / 1e12, 2),
+        "frames_per_s": round(frames_per_step * args.steps / elapsed, 4),
+        "tflops_whole_net": round(frames_per_step * args.steps * frame_flops / elapsed / 1e12, 2),
     }
     if k_ms > 0:
         achieved = k_flops / (k_ms * 1e-3) / 1e12
         peak = PEAK_TFLOPS[dtype]
         result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                              "frac": round(achieved / peak, 4), "traffic": None,
+                              "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.workload),
                               "kernel": "conv3x3_mfma_kernel (345 dense-block convs per frame)",
                               "avg_launch_us": round(1e3 * k_ms / max(k_launches, 1), 2), "launches": int(k_launches)}
 
     if rank == 0:
         # host-to-host enhance() (PCIe + quantisation inclusive), reported beside the metric, never as `value`
         log(f"timed region done: {elapsed:.3f} s for {args.steps} steps")
+        up.enhance(frame)                                  # warm (workspace for the u8 path)
         t1 = time.perf_counter()
         out_u8, _ = up.enhance(frame)
         torch.cuda.synchronize(dev)

@@ -19,9 +19,11 @@
 //                               s_barrier             -> everyone's have; all finished compute(c-1)
 //                               issue w(c+1), in(c+2) into the slots last read in iteration c-1
 //                               compute(c)
-//   LDS image : input slot = [padded pixel][32 B]; the two 16-byte halves of pixel p are swapped
-//               when bit 3 of p is set (applied on the DMA source address and on the read), which
-//               makes the 16-lane ds_read_b128 groups conflict-free.
+//   LDS image : input slot = [padded pixel][32 B]; the two 16-byte halves of a pixel are swapped
+//               when bit 3 of its padded column is set (applied on the DMA source address and on the
+//               read), which makes the 16-lane ds_read_b128 groups conflict-free; the key depends on
+//               the column only, so a lane needs one address per horizontal tap and the six rows
+//               are immediate offsets.
 //   operands  : for one horizontal tap dx the wave reads 6 pixel fragments (rows -1..4) once and
 //               uses each for up to 3 vertical taps: 6 + 3*NT ds_read_b128 per 12*NT MFMAs; the next
 //               step's fragments are read during the current step's MFMAs (sched_barrier-pinned).
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_xl_kernel(ConvArgs a) {
     const int y0 = ty * TH, x0 = tx * TW;
 
     // ---- LDS-DMA sources.  LDS item k of an input slot = padded pixel k>>1, 16-byte slot k&1; it
-    // holds channel half (k&1) ^ bit3(pixel) of that pixel's chunk.
+    // holds channel half (k&1) ^ bit3(padded column) of that pixel's chunk.
     const char* zero_page = static_cast<const char*>(a.zeros);
     const char* isrc[IN_ROUNDS];
     unsigned live = 0, present = 0;
@@ -116,8 +118,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_xl_kernel(ConvArgs a) {
         for (int i = 0; i < IN_ROUNDS; ++i) {
             const int k = tid + 512 * i;
             const int p = k >> 1;
-            const int half = (k & 1) ^ ((p >> 3) & 1);
             const int py = p / PW, px = p - py * PW;
+            const int half = (k & 1) ^ ((px >> 3) & 1);
             const int Y = y0 - 1 + py, X = x0 - 1 + px;
             const bool has = k < IN_ITEMS;
             const bool ok = has && Y >= 0 && Y < a.h && X >= 0 && X < a.w_;
@@ -161,7 +163,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_xl_kernel(ConvArgs a) {
 
     // ---- per-lane operand coordinates
     const int m = lane & 31, hh = lane >> 5;
-    const int p_row0 = (4 * wave) * PW + m;           // padded pixel of (row 0 of this wave's 6, col m, dx 0)
+    // byte offset inside an input slot of this lane's fragment for horizontal tap dx, row 0 of the wave's 6
+    int p_off[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) p_off[dx] = ((4 * wave) * PW + m + dx) * 32 + ((hh ^ (((m + dx) >> 3) & 1)) << 4);
     const int w_off = hh * (32 * NT) + m;             // item index inside a weight slot
     // waves whose 4 rows are all below the image do no arithmetic (edge tiles), but still stage and barrier
     const bool active = (y0 + 4 * wave) < a.h;
@@ -196,8 +201,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_xl_kernel(ConvArgs a) {
             const char* st = smem + islot * IN_BYTES;
             const f32x4* sw = reinterpret_cast<const f32x4*>(smem + WRING + (c & 1) * W_BYTES);
             auto pix_frag = [&](int r, int dx) -> f32x4 {
-                const int p = p_row0 + r * PW + dx;
-                return *reinterpret_cast<const f32x4*>(st + p * 32 + ((hh ^ ((p >> 3) & 1)) << 4));
+                return *reinterpret_cast<const f32x4*>(st + p_off[dx] + r * (PW * 32));
             };
             f32x4 P[2][6];
             f32x4 Wf[2][NT];

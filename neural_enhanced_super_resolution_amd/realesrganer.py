@@ -30,6 +30,17 @@ def _bgr2gray(img):
     return (img[..., 0] * np.float32(0.114) + img[..., 1] * np.float32(0.587) + img[..., 2] * np.float32(0.299)).astype(np.float32)
 
 
+_U8_LUT = np.arange(256, dtype=np.float32) / 255     # exactly enhance()'s `img.astype(float32) / 255`
+
+
+def normalize_u8_on_device(x):
+    """uint8 tensor -> float32 in [0,1] with numpy's correctly rounded division.  (torch divides by a
+    Python scalar on the GPU by multiplying with its reciprocal, which is 1 ulp off for some of the 256
+    values -- enough to flip a rounding tie 351 layers later.)"""
+    lut = torch.from_numpy(_U8_LUT).to(x.device)
+    return lut[x.long()]
+
+
 def _gray2rgb(img):
     return np.repeat(img[:, :, None], 3, axis=2)
 
@@ -117,7 +128,11 @@ class RealESRGANer:
     def pre_process(self, img):
         """HWC float32 RGB [0,1] -> self.img [1,3,H,W] on device; reflect pre-pad; pad to mod_scale."""
         img = torch.from_numpy(np.transpose(img, (2, 0, 1))).float()
-        self.img = img.unsqueeze(0).to(self.device)
+        self._pad_on_device(img.unsqueeze(0).to(self.device))
+
+    def _pad_on_device(self, x):
+        """The device-side half of upstream's pre_process: x is [1,3,H,W] float on self.device."""
+        self.img = x
         if self.half:
             self.img = self.img.half()
         if self.pre_pad != 0:
@@ -156,6 +171,14 @@ class RealESRGANer:
                 grid.append(((py0, py1, px0, px1), (iy0 * s, iy1 * s, ix0 * s, ix1 * s), (cy0, cy0 + th * s, cx0, cx0 + tw * s)))
         return grid
 
+    def batch_for(self, th, tw, ntiles):
+        """Tiles of th x tw input evaluated per forward call: at most ``tile_batch``, and on the HIP
+        backend the count whose workgroups fill the CUs most evenly (values do not depend on it)."""
+        nb = max(1, min(int(self.tile_batch), ntiles))
+        if nb > 1 and isinstance(self.model, RRDBNet) and self.device.type == "cuda":
+            nb = self.model.preferred_batch(self.device, th, tw, nb)
+        return nb
+
     def tile_process(self):
         """Runs the network on overlapping tiles and pastes the un-padded centres (upstream
         semantics, tile for tile).  Equal-shaped tiles are evaluated ``tile_batch`` at a time in one
@@ -168,12 +191,8 @@ class RealESRGANer:
         for t in grid:
             (py0, py1, px0, px1) = t[0]
             groups.setdefault((py1 - py0, px1 - px0), []).append(t)
-        nb_max = max(1, int(self.tile_batch)) if batch == 1 else 1
         for (th, tw), tiles in groups.items():
-            nb = nb_max
-            if nb > 1 and isinstance(self.model, RRDBNet) and self.img.device.type == "cuda":
-                # occupancy-aware grouping: a batch whose workgroup count is a multiple of the CU count
-                nb = self.model.preferred_batch(self.img.device, th, tw, min(nb_max, len(tiles)))
+            nb = self.batch_for(th, tw, len(tiles)) if batch == 1 else 1
             for i in range(0, len(tiles), nb):
                 chunk = tiles[i:i + nb]
                 if len(chunk) == 1:
@@ -218,6 +237,23 @@ class RealESRGANer:
         if h % ms or w % ms:
             return False
         return self.model.num_in_ch == 3 and self.model.num_out_ch == 3 and self.model.out_scale() == self.scale
+
+    def _u8_on_device_ok(self, img):
+        """8-bit BGR frames on the HIP backend (any tiling / padding): the uint8 frame is uploaded
+        (4x fewer bytes than float), normalised, padded, tiled, clamped and quantised on the GPU with
+        the same float32 operations enhance() performs in numpy, and only uint8 comes back."""
+        return (isinstance(self.model, RRDBNet) and self.device.type == "cuda" and img.dtype == np.uint8
+                and img.ndim == 3 and img.shape[2] == 3)
+
+    @torch.no_grad()
+    def _enhance_u8_on_device(self, img):
+        x = torch.from_numpy(np.ascontiguousarray(img)).to(self.device)            # H2D: uint8 HWC BGR
+        x = normalize_u8_on_device(x.permute(2, 0, 1).flip(0)).unsqueeze(0)          # BGR->RGB, /255 (f32), HWC->NCHW
+        self._pad_on_device(x)
+        out = self._run()                                                            # [1,3,H*s,W*s] RGB
+        out = out.data.squeeze(0).float().clamp_(0, 1)
+        q = (out.flip(0).permute(1, 2, 0) * 255.0).round().to(torch.uint8)           # RGB->BGR, CHW->HWC, x255, round
+        return q.contiguous().cpu().numpy()
 
     @torch.no_grad()
     def enhance_float(self, img):
@@ -268,6 +304,9 @@ class RealESRGANer:
             # /255, BGR->RGB, network, clamp, RGB->BGR, x255, round -- all inside the HIP path
             x = torch.from_numpy(np.ascontiguousarray(img)).to(self.device)
             output = self.model.forward_u8(x, flip_rgb=True, round_nearest=True).cpu().numpy()
+            img_mode = "RGB"
+        elif self._u8_on_device_ok(img):
+            output = self._enhance_u8_on_device(img)
             img_mode = "RGB"
         else:
             output_img, img_mode, max_range = self.enhance_float(img)

@@ -22,6 +22,8 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from .realesrganer import normalize_u8_on_device
+
 
 @dataclass(frozen=True)
 class Tile:
@@ -134,14 +136,14 @@ def enhance_sharded(up, band, frame_hw, group=None, gather=True):
     mine = [t for t, o in zip(tiles, owner) if o == rank]
     results = []
     if mine:
-        x = local.permute(2, 0, 1).flip(0).float().div(255.0).unsqueeze(0)   # BGR->RGB, /255, HWC->NCHW
+        x = normalize_u8_on_device(local.permute(2, 0, 1).flip(0)).unsqueeze(0)   # BGR->RGB, /255, HWC->NCHW
         if up.half:
             x = x.half()
         groups = {}
         for t in mine:
             groups.setdefault((t.inp[1] - t.inp[0], t.inp[3] - t.inp[2]), []).append(t)
-        nb = max(1, int(getattr(up, "tile_batch", 1)))
-        for ts in groups.values():
+        for (th, tw), ts in groups.items():
+            nb = up.batch_for(th, tw, len(ts))
             for i in range(0, len(ts), nb):
                 chunk = ts[i:i + nb]
                 inp = torch.cat([x[:, :, t.inp[0] - n0:t.inp[1] - n0, t.inp[2]:t.inp[3]] for t in chunk], 0)

@@ -161,3 +161,17 @@ def test_translation_property_full_net(cuda_device):
     y1 = net(torch.roll(x, shifts=(2, 2), dims=(2, 3)))
     m = 88   # > receptive-field radius of the 1-block net at output resolution (17 trunk px * 4 + upsampler convs)
     assert torch.equal(y1[:, :, m + 4:-m, m + 4:-m], y0[:, :, m:-m - 4, m:-m - 4])
+
+
+@pytest.mark.parametrize("kw", [dict(tile=32, tile_pad=10, pre_pad=0), dict(tile=32, tile_pad=10, pre_pad=10), dict(tile=0, tile_pad=10, pre_pad=10)])
+@pytest.mark.parametrize("hw", [(64, 96), (63, 95)])
+def test_u8_device_pipeline_equals_host_float_path(cuda_device, kw, hw):
+    """enhance() keeps 8-bit frames on the GPU end to end; its bytes must equal the upstream-shaped
+    host path (enhance_float + numpy quantisation)."""
+    sd = synthetic_state_dict(seed=3, num_in_ch=3, scale=2, num_block=2)
+    up = RealESRGANer(scale=2, model_path={"params_ema": sd}, model=RRDBNet(3, 3, scale=2, num_block=2), device=cuda_device, **kw)
+    img = synthetic_frame(hw[0], hw[1], seed=6)
+    assert up._u8_on_device_ok(img)
+    got, mode = up.enhance(img)
+    f, _, _ = up.enhance_float(img)
+    assert mode == "RGB" and np.array_equal(got, (f * 255.0).round().astype(np.uint8))
