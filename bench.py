@@ -60,9 +60,10 @@ def host_threads(cap=16):
 
 
 def pmc_traffic(workload):
-    """HBM bytes per launch of the dominant kernel family from the committed rocprofv3 PMC passes
-    (FETCH_SIZE x 2 -- the gfx950 correction of MI355X_MICROARCH.md -- plus WRITE_SIZE); PMC counters
-    cannot be collected inside this process, so the figure comes from profiles/ (null if absent)."""
+    """HBM bytes per conv launch (average over the 351 launches of one frame) from the committed
+    rocprofv3 PMC passes profiles/r01/final_c2_pmc_fetch_write.txt: FETCH_SIZE x 2 (the gfx950
+    correction of MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, two separate --pmc passes.  PMC
+    counters cannot be collected inside this process, so the figure comes from profiles/ (null if absent)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
