@@ -34,6 +34,8 @@
 //               instruction writes 1 KiB of whole lines.
 #include <hip/hip_bf16.h>
 
+#include <cstdlib>
+
 #include "nesr_kernels.h"
 
 namespace nesr {
@@ -45,11 +47,22 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int TH = 32, TW = 32, PH = 34, PW = 34;
-constexpr int NPIX = PH * PW;                       // 1156 padded pixels
-constexpr int IN_ITEMS = 2 * NPIX;                  // 2312 16-byte items per input slot
-constexpr int IN_ROUNDS = (IN_ITEMS + 511) / 512;   // 5 DMA rounds of 512 lanes
-constexpr int IN_BYTES = IN_ITEMS * 16;             // 36992
+constexpr int TW = 32, PW = 34;
+
+// Geometry of one instantiation: WAVES waves (4 output rows each), an input ring of ISLOTS slots.
+//   <8 waves, 3 slots>: 32x32-pixel tiles, one workgroup per CU  (least staged bytes per FLOP)
+//   <4 waves, 3|2 slots>: 16x32-pixel tiles, two independent workgroups per CU (each one's DMA
+//                         prologue and store epilogue overlap the other's MFMAs)
+template <int WAVES>
+struct Geo {
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int TH = 4 * WAVES;
+    static constexpr int PH = TH + 2;
+    static constexpr int NPIX = PH * PW;                                // padded pixels
+    static constexpr int IN_ITEMS = 2 * NPIX;                           // 16-byte items per input slot
+    static constexpr int IN_ROUNDS = (IN_ITEMS + THREADS - 1) / THREADS;
+    static constexpr int IN_BYTES = IN_ITEMS * 16;
+};
 
 typedef __attribute__((address_space(3))) char lds_char;
 
@@ -81,12 +94,16 @@ __device__ __forceinline__ void glds16_asm(const char* gsrc, unsigned lds_dst) {
         : "memory");
 }
 
-template <int NT>
-__global__ __launch_bounds__(512, 2) void conv3x3_bf16_xl_kernel(ConvArgs a) {
+template <int NT, int WAVES, int ISLOTS>
+__global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_bf16_xl_kernel(ConvArgs a) {
+    typedef Geo<WAVES> G;
+    constexpr int THREADS = G::THREADS, TH = G::TH;
+    constexpr int IN_ITEMS = G::IN_ITEMS, IN_ROUNDS = G::IN_ROUNDS, IN_BYTES = G::IN_BYTES;
     constexpr int W_ITEMS = 9 * 2 * 32 * NT;
-    constexpr int W_ROUNDS = (W_ITEMS + 511) / 512;
+    constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
     constexpr int W_BYTES = W_ITEMS * 16;
-    constexpr int WRING = 3 * IN_BYTES;   // LDS: [input ring: 3 x IN_BYTES][weight ring: 2 x W_BYTES]
+    constexpr int WRING = ISLOTS * IN_BYTES;   // LDS: [input ring: ISLOTS x IN_BYTES][weight ring: 2 x W_BYTES]
+    constexpr int AHEAD = ISLOTS - 1;          // input chunks in flight ahead of the one being computed
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -116,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_xl_kernel(ConvArgs a) {
         const char* in = static_cast<const char*>(a.in);
 #pragma unroll
         for (int i = 0; i < IN_ROUNDS; ++i) {
-            const int k = tid + 512 * i;
+            const int k = tid + THREADS * i;
             const int p = k >> 1;
             const int py = p / PW, px = p - py * PW;
             const int half = (k & 1) ^ ((px >> 3) & 1);
@@ -137,30 +154,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_xl_kernel(ConvArgs a) {
     // must be known exactly: rounds in which the wave has no item at all are skipped by a
     // wave-uniform (scalar) branch, partial waves run the instruction with partial EXEC.
     const unsigned lds_base = (unsigned)(size_t)(lds_char*)(smem);
-    const int nin = (IN_ITEMS - wave * 64 + 511) / 512;   // input DMA instructions of this wave per chunk (4 or 5)
-    const int nwt = (W_ITEMS - wave * 64 + 511) / 512;
-    auto issue_in = [&](int c, int slot) {
-        const unsigned dst = lds_base + slot * IN_BYTES + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < IN_ROUNDS; ++i) {
-            if (i < nin) {
-                const char* s = isrc[i] + (((live >> i) & 1u) ? (long long)c * in_cstride : 0ll);
-                if ((present >> i) & 1u) glds16_asm(s, __builtin_amdgcn_readfirstlane(dst + i * 8192));
-            }
+    const int nin = (IN_ITEMS - wave * 64 + THREADS - 1) / THREADS;   // input DMA instructions of this wave per chunk
+    const int nwt = (W_ITEMS - wave * 64 + THREADS - 1) / THREADS;
+    auto issue_in_round = [&](int c, int slot, int i) {   // i is a compile-time constant at every call site
+        if (i < nin) {
+            const unsigned dst = lds_base + slot * IN_BYTES + wave * 1024;
+            const char* s = isrc[i] + (((live >> i) & 1u) ? (long long)c * in_cstride : 0ll);
+            if ((present >> i) & 1u) glds16_asm(s, __builtin_amdgcn_readfirstlane(dst + i * (THREADS * 16)));
         }
+    };
+    auto issue_w_round = [&](int c, int slot, int i) {
+        if (i < nwt) {
+            const unsigned dst = lds_base + WRING + slot * W_BYTES + wave * 1024;
+            const int k = tid + THREADS * i;
+            if (k < W_ITEMS) glds16_asm(wbase + (size_t)c * W_BYTES + k * 16, __builtin_amdgcn_readfirstlane(dst + i * (THREADS * 16)));
+        }
+    };
+    auto issue_in = [&](int c, int slot) {
+#pragma unroll
+        for (int i = 0; i < IN_ROUNDS; ++i) issue_in_round(c, slot, i);
     };
     auto issue_w = [&](int c, int slot) {
-        const unsigned dst = lds_base + WRING + slot * W_BYTES + wave * 1024;
-        const char* wc = wbase + (size_t)c * W_BYTES;
 #pragma unroll
-        for (int i = 0; i < W_ROUNDS; ++i) {
-            if (i < nwt) {
-                const int k = tid + 512 * i;
-                if (k < W_ITEMS) glds16_asm(wc + k * 16, __builtin_amdgcn_readfirstlane(dst + i * 8192));
-            }
-        }
+        for (int i = 0; i < W_ROUNDS; ++i) issue_w_round(c, slot, i);
     };
-
     // ---- per-lane operand coordinates
     const int m = lane & 31, hh = lane >> 5;
     // byte offset inside an input slot of this lane's fragment for horizontal tap dx, row 0 of the wave's 6
@@ -180,14 +197,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_xl_kernel(ConvArgs a) {
             for (int e = 0; e < 16; ++e) acc[r][t][e] = 0.f;
 
     const int nchunks = a.cin / 16;
-    // prologue: in(0), w(0), in(1) -- the loop's first wait leaves exactly in(1) in flight
+    // prologue: in(0), w(0) [, in(1)] -- the loop's first wait leaves exactly the AHEAD-1 newest input
+    // chunks in flight
     issue_in(0, 0);
     issue_w(0, 0);
-    if (nchunks > 1) issue_in(1, 1);
-    int islot = 0, ifill = 2;
+    if (AHEAD >= 2 && nchunks > 1) issue_in(1, 1);
+    int islot = 0, ifill = AHEAD >= 2 ? 2 : 1;
     for (int c = 0; c < nchunks; ++c) {
-        // all of this wave's DMAs except in(c+1) (its nin newest instructions) must have landed
-        if (c + 1 >= nchunks)
+        // everything of this wave except the input chunks still ahead (AHEAD-1 of them, nin
+        // instructions each) must have landed: w(c) and in(c)
+        if (AHEAD < 2 || c + 1 >= nchunks)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (nin == IN_ROUNDS)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IN_ROUNDS) : "memory");
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_xl_kernel(ConvArgs a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (c + 1 < nchunks) issue_w(c + 1, (c + 1) & 1);
-        if (c + 2 < nchunks) issue_in(c + 2, ifill);
+        if (c + AHEAD < nchunks) issue_in(c + AHEAD, ifill);
         if (active) {
             const char* st = smem + islot * IN_BYTES;
             const f32x4* sw = reinterpret_cast<const f32x4*>(smem + WRING + (c & 1) * W_BYTES);
@@ -234,8 +253,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_xl_kernel(ConvArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        islot = islot == 2 ? 0 : islot + 1;
-        ifill = ifill == 2 ? 0 : ifill + 1;
+        islot = islot == ISLOTS - 1 ? 0 : islot + 1;
+        ifill = ifill == ISLOTS - 1 ? 0 : ifill + 1;
     }
     if (!active) return;
 
@@ -332,18 +351,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_xl_kernel(ConvArgs a) {
     }
 }
 
-template <int NT>
+template <int NT, int WAVES, int ISLOTS>
 hipError_t launch_xl(const ConvArgs& a, hipStream_t s) {
-    constexpr size_t shm = 3 * (size_t)IN_BYTES + 2 * (size_t)(9 * 2 * 32 * NT * 16);
+    typedef Geo<WAVES> G;
+    constexpr size_t shm = (size_t)ISLOTS * G::IN_BYTES + 2 * (size_t)(9 * 2 * 32 * NT * 16);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_xl_kernel<NT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_xl_kernel<NT, WAVES, ISLOTS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int tiles = ((a.w_ + TW - 1) / TW) * ((a.h + TH - 1) / TH) * a.n;
-    hipLaunchKernelGGL((conv3x3_bf16_xl_kernel<NT>), dim3(tiles), dim3(512), shm, s, a);
+    const int tiles = ((a.w_ + TW - 1) / TW) * ((a.h + G::TH - 1) / G::TH) * a.n;
+    hipLaunchKernelGGL((conv3x3_bf16_xl_kernel<NT, WAVES, ISLOTS>), dim3(tiles), dim3(G::THREADS), shm, s, a);
     return hipGetLastError();
 }
 
@@ -353,8 +373,17 @@ hipError_t launch_conv3x3_bf16_xl(const ConvArgs& a, hipStream_t s) {
     if (a.cin % 16 || !a.zeros) return hipErrorInvalidValue;
     // the 16-byte accesses of the pair image / wide stores need pixel strides of whole 8-channel groups
     if (a.in_map.pix % 8 || (a.out && (a.out_map.pix % 8 || a.out_coff % 16))) return hipErrorInvalidValue;
-    if (a.coutp == 64) return launch_xl<2>(a, s);
-    if (a.coutp == 32) return launch_xl<1>(a, s);
+    static const int geo = [] {   // NESR_XL_GEOMETRY=8 (32x32 tiles, 1 WG/CU) | 4 (16x32 tiles, 2 WGs/CU)
+        const char* e = getenv("NESR_XL_GEOMETRY");
+        return e ? atoi(e) : 4;
+    }();
+    if (geo == 8) {
+        if (a.coutp == 64) return launch_xl<2, 8, 3>(a, s);
+        if (a.coutp == 32) return launch_xl<1, 8, 3>(a, s);
+    } else {
+        if (a.coutp == 64) return launch_xl<2, 4, 2>(a, s);   // 2 x 19.6 + 2 x 18.4 = 76 KB -> 2 per CU
+        if (a.coutp == 32) return launch_xl<1, 4, 3>(a, s);   // 3 x 19.6 + 2 x 9.2 = 77 KB -> 2 per CU
+    }
     return hipErrorInvalidValue;
 }
 

@@ -534,11 +534,13 @@ int nesr_preferred_batch(const nesr_ctx* c, int H, int W, int max_batch) {
     const int h = (H + u - 1) / u, w = (W + u - 1) / u;
     // workgroups per frame of the trunk convs (the kernel choice mirrors launch_conv3x3_bf16)
     const bool xl = c->dtype == NESR_DTYPE_BF16 && (long)h * w > 256L * 256L;
-    const long per = xl ? (long)((h + 31) / 32) * ((w + 31) / 32) : (long)((h + 7) / 8) * ((w + 15) / 16);
+    static const int geo = [] { const char* e = getenv("NESR_XL_GEOMETRY"); return e ? atoi(e) : 4; }();
+    const int xl_th = geo == 8 ? 32 : 16;
+    const long per = xl ? (long)((h + xl_th - 1) / xl_th) * ((w + 31) / 32) : (long)((h + 7) / 8) * ((w + 15) / 16);
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    const long slots = (long)cus * (xl ? 1 : 2);   // co-resident workgroups
+    const long slots = (long)cus * ((xl && geo == 8) ? 1 : 2);   // co-resident workgroups
     auto eff = [&](int b) {
         const long wgs = per * b;
         return (double)wgs / (double)(((wgs + slots - 1) / slots) * slots);

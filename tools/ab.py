@@ -54,24 +54,30 @@ def main():
     args = ap.parse_args()
     dt = 1 if args.dtype == "bf16" else 0
     sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=2)
+    x = torch.rand(args.batch, 3, args.hw, args.hw, device="cuda")
+    y = [torch.empty(args.batch, 3, 2 * args.hw, 2 * args.hw, device="cuda") for _ in range(2)]
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     libs, ctxs = [], []
-    for path, env in ((args.a, args.env_a), (args.b, args.env_b)):
+
+    def run(i):
+        rc = libs[i].nesr_forward(ctxs[i], ctypes.c_void_p(x.data_ptr()), args.batch, 3, args.hw, args.hw,
+                                  ctypes.c_void_p(y[i].data_ptr()), stream)
+        assert rc == 0, libs[i].nesr_last_error()
+
+    # the libraries read their NESR_* switches at context creation / first launch: keep each
+    # variant's environment set through its first forward (use two copies of the file to compare
+    # switches of one build -- dlopen returns the same handle for the same path)
+    for i, (path, env) in enumerate(((args.a, args.env_a), (args.b, args.env_b))):
         kvs = [kv.split("=") for kv in env.split(",") if kv]
         for k, v in kvs:
             os.environ[k] = v
         lib = load(os.path.abspath(path))
         libs.append(lib)
         ctxs.append(make_ctx(lib, sd, dt))
+        run(i)
+        torch.cuda.synchronize()
         for k, _ in kvs:
             os.environ.pop(k, None)
-    x = torch.rand(args.batch, 3, args.hw, args.hw, device="cuda")
-    y = [torch.empty(args.batch, 3, 2 * args.hw, 2 * args.hw, device="cuda") for _ in range(2)]
-    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-    def run(i):
-        rc = libs[i].nesr_forward(ctxs[i], ctypes.c_void_p(x.data_ptr()), args.batch, 3, args.hw, args.hw,
-                                  ctypes.c_void_p(y[i].data_ptr()), stream)
-        assert rc == 0, libs[i].nesr_last_error()
 
     for i in (0, 1):
         run(i)
