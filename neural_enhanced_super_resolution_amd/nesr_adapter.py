@@ -1,0 +1,198 @@
+"""GPU versions of the NESR pipeline's ESRGAN call sites (SURVEY.md section 8(a) rows a16-a19,
+section 8(f) row 2): everything between "HWC uint8 RGB ndarray in" and "HWC uint8 RGB ndarray out"
+runs on the device -- 12-channel synthesis, the network (``upscaler.model``, the reference's own way of
+calling it), the truncating quantiser, and the NESR tiler with its Lanczos resize.
+
+Reference (all in nesr/nesr.py):
+  _apply_esrgan                 :754-843   dispatch by megapixels / device, 12-ch vs 3-ch, tiling
+  _apply_esrgan_12channel       :845-903   [img, clamp(1.1 img), clamp(0.9 img), GaussianBlur3x3(img)] -> model
+  _apply_esrgan_3channel        :905-945   img repeated 4x -> model
+  _process_with_tiling          :311-475   ceil grid, +-padding windows, crop, Lanczos resize to the canvas
+
+Differences, on purpose: no exception ladder (nesr.py:815-843, 448-473 turn any backend failure into a
+bicubic result -- here failures raise), no MPS branches, no probe tile (nesr.py:349-357 runs the
+processor on a 256x256 corner and discards the result).
+
+cv2 is not available offline, so its two non-trivial image ops are restated, PARITY UNPINNED:
+  * cv2.GaussianBlur(u8, (3,3), 0): kernel [1 2 1]/4 separable, BORDER_REFLECT_101, fixed-point with
+    round-half-up -> (S + 8) >> 4 on the 16-weight integer sum.
+  * cv2.resize(..., INTER_LANCZOS4): cv2's coefficient formula (interpolateLanczos4) and sampling
+    geometry, evaluated in float32 (cv2 uses 11-bit fixed-point coefficients: expect +-1 LSB).
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+from torch.nn import functional as F
+
+from .realesrganer import normalize_u8_on_device
+
+
+# ----------------------------------------------------------------------------- 12-channel builder
+def gaussian_blur3x3_u8(img):
+    """img: uint8 [H, W, C] tensor -> uint8, cv2.GaussianBlur(img, (3, 3), 0) restated (see module doc)."""
+    x = img.permute(2, 0, 1).unsqueeze(0).to(torch.int32)
+    h, w = x.shape[-2:]
+    if h > 1 and w > 1:
+        xp = F.pad(x.float(), (1, 1, 1, 1), mode="reflect").to(torch.int32)     # BORDER_REFLECT_101
+    else:
+        xp = F.pad(x.float(), (1, 1, 1, 1), mode="replicate").to(torch.int32)
+    hs = xp[..., :, 0:-2] + 2 * xp[..., :, 1:-1] + xp[..., :, 2:]
+    s = hs[..., 0:-2, :] + 2 * hs[..., 1:-1, :] + hs[..., 2:, :]
+    return ((s + 8) >> 4).clamp_(0, 255).to(torch.uint8).squeeze(0).permute(1, 2, 0)
+
+
+def build_12channel(image_rgb, device):
+    """nesr.py:851-882: RGB u8 -> [1, 12, H, W] float32 on device
+    = [bgr/255, clamp(1.1 bgr/255), clamp(0.9 bgr/255), GaussianBlur3x3(bgr)/255]."""
+    bgr = torch.as_tensor(np.ascontiguousarray(image_rgb)).to(device).flip(2)            # cv2.COLOR_RGB2BGR
+    t = normalize_u8_on_device(bgr.permute(2, 0, 1))                                       # /255.0
+    blurred = normalize_u8_on_device(gaussian_blur3x3_u8(bgr).permute(2, 0, 1))
+    return torch.cat([t, torch.clamp(t * 1.1, 0, 1), torch.clamp(t * 0.9, 0, 1), blurred], 0).unsqueeze(0)
+
+
+def build_3channel_x4(image_rgb, device):
+    """nesr.py:915-927: RGB u8 -> [1, 12, H, W] = the BGR/255 image repeated 4 times."""
+    bgr = torch.as_tensor(np.ascontiguousarray(image_rgb)).to(device).flip(2)
+    t = normalize_u8_on_device(bgr.permute(2, 0, 1))
+    return torch.cat([t, t, t, t], 0).unsqueeze(0)
+
+
+def quantize_trunc_to_rgb(output):
+    """nesr.py:894-901: [1,3,H,W] float -> HWC uint8 RGB: x*255, clip(0,255), truncating astype, BGR->RGB."""
+    out = output.squeeze(0).float()
+    q = (out.permute(1, 2, 0) * 255.0).clamp_(0, 255).to(torch.uint8)
+    return q.flip(2)
+
+
+@torch.no_grad()
+def apply_esrgan_12channel(upscaler, image_rgb, as_numpy=True):
+    """_apply_esrgan_12channel (nesr.py:845-903) with every step on the GPU."""
+    model = upscaler.model
+    model.eval()
+    y = model(build_12channel(image_rgb, upscaler.device))
+    q = quantize_trunc_to_rgb(y)
+    return q.cpu().numpy() if as_numpy else q
+
+
+@torch.no_grad()
+def apply_esrgan_3channel(upscaler, image_rgb, as_numpy=True):
+    """_apply_esrgan_3channel (nesr.py:905-945)."""
+    model = upscaler.model
+    model.eval()
+    y = model(build_3channel_x4(image_rgb, upscaler.device))
+    q = quantize_trunc_to_rgb(y)
+    return q.cpu().numpy() if as_numpy else q
+
+
+# ----------------------------------------------------------------------------- Lanczos-4 resize
+def _lanczos4_coeffs(frac):
+    """cv2 interpolateLanczos4 for a float32 tensor of fractional offsets -> [..., 8] weights."""
+    s45 = 0.70710678118654752440084436210485
+    cs = torch.tensor([[1, 0], [-s45, -s45], [0, 1], [s45, -s45], [-1, 0], [s45, s45], [0, -1], [-s45, s45]],
+                      dtype=torch.float64, device=frac.device)
+    x = frac.to(torch.float64)
+    y0 = -(x + 3) * (math.pi * 0.25)
+    s0, c0 = torch.sin(y0), torch.cos(y0)
+    i = torch.arange(8, device=frac.device, dtype=torch.float64)
+    y = -(x[..., None] + 3 - i) * (math.pi * 0.25)
+    co = ((cs[:, 0] * s0[..., None] + cs[:, 1] * c0[..., None]) / (y * y)).to(torch.float32)
+    co = co * (1.0 / co.sum(-1, keepdim=True))
+    exact = (frac < 1.1920929e-07)[..., None]
+    delta = torch.zeros(8, device=frac.device)
+    delta[3] = 1.0
+    return torch.where(exact, delta.expand_as(co), co)
+
+
+def lanczos4_resize_u8(img, out_h, out_w):
+    """img uint8 [H, W, C] tensor -> uint8 [out_h, out_w, C]; cv2.resize(INTER_LANCZOS4) geometry."""
+    h, w, c = img.shape
+    x = img.permute(2, 0, 1).float()
+
+    def axis(n_in, n_out):
+        scale = n_in / n_out
+        pos = (torch.arange(n_out, device=img.device, dtype=torch.float32) + 0.5) * scale - 0.5
+        i0 = torch.floor(pos)
+        frac = pos - i0
+        idx = (i0.long()[:, None] + torch.arange(-3, 5, device=img.device)).clamp_(0, n_in - 1)   # replicate border
+        return idx, _lanczos4_coeffs(frac)
+
+    ix, wx = axis(w, out_w)
+    iy, wy = axis(h, out_h)
+    tmp = (x[:, :, ix] * wx).sum(-1)                       # [C, H, out_w]
+    out = (tmp[:, iy, :] * wy[None, :, :, None]).sum(2)    # [C, out_h, out_w]
+    return out.round_().clamp_(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous()
+
+
+# ----------------------------------------------------------------------------- NESR tiler + dispatcher
+@torch.no_grad()
+def process_with_tiling(processor, image_rgb, tile_size, padding, upscale_factor, device):
+    """_process_with_tiling (nesr.py:311-475): `processor(tile_rgb_u8 ndarray|tensor) -> uint8 tensor`.
+    Returns an HWC uint8 RGB ndarray of size int(h*uf) x int(w*uf)."""
+    h, w, c = image_rgb.shape
+    if h <= tile_size and w <= tile_size:
+        return processor(image_rgb).cpu().numpy()
+    nth, ntw = math.ceil(h / tile_size), math.ceil(w / tile_size)
+    out_h, out_w = int(h * upscale_factor), int(w * upscale_factor)
+    canvas = torch.zeros((out_h, out_w, c), dtype=torch.uint8, device=device)
+    for i in range(nth):
+        for j in range(ntw):
+            y0, y1 = max(0, i * tile_size - padding), min(h, (i + 1) * tile_size + padding)
+            x0, x1 = max(0, j * tile_size - padding), min(w, (j + 1) * tile_size + padding)
+            tile = image_rgb[y0:y1, x0:x1]
+            pt = processor(tile)
+            oy0, oy1 = int(y0 * upscale_factor), int(y1 * upscale_factor)
+            ox0, ox1 = int(x0 * upscale_factor), int(x1 * upscale_factor)
+            if padding > 0:
+                pu = int(padding * upscale_factor)
+                if y0 > 0:
+                    oy0 += pu
+                if y1 < h:
+                    oy1 -= pu
+                if x0 > 0:
+                    ox0 += pu
+                if x1 < w:
+                    ox1 -= pu
+            th, tw = pt.shape[:2]
+            sy, sx = th / tile.shape[0], tw / tile.shape[1]
+            ty0 = 0 if y0 == 0 else int(padding * sy)
+            ty1 = th if y1 == h else int(th - padding * sy)
+            tx0 = 0 if x0 == 0 else int(padding * sx)
+            tx1 = tw if x1 == w else int(tw - padding * sx)
+            ty0 = max(0, min(ty0, th - 1))
+            ty1 = max(ty0 + 1, min(ty1, th))
+            tx0 = max(0, min(tx0, tw - 1))
+            tx1 = max(tx0 + 1, min(tx1, tw))
+            oh, ow = oy1 - oy0, ox1 - ox0
+            if oh <= 0 or ow <= 0:
+                continue
+            region = pt[ty0:ty1, tx0:tx1]
+            if region.shape[0] != oh or region.shape[1] != ow:
+                region = lanczos4_resize_u8(region, oh, ow)     # cv2.resize(..., INTER_LANCZOS4), nesr.py:438-443
+            canvas[oy0:oy1, ox0:ox1] = region
+    return canvas.cpu().numpy()
+
+
+def apply_esrgan(upscaler, image_rgb, config=None, device_kind="cuda"):
+    """_apply_esrgan (nesr.py:754-813): the reference's dispatch, minus its fallback ladder.
+    config keys as the reference's: enable_tiling, force_3channel, max_tile_size, upscale_factor,
+    cuda_megapixel_threshold (the reference's literal default for cuda is 8)."""
+    cfg = {"enable_tiling": True, "force_3channel": False, "max_tile_size": 512, "upscale_factor": 2.0}
+    cfg.update(config or {})
+    h, w, _ = image_rgb.shape
+    megapixels = (h * w) / (1024 * 1024)
+    use_tiling = False
+    if cfg["enable_tiling"]:
+        thr = {"cpu": cfg.get("cpu_megapixel_threshold", 2), "mps": cfg.get("mps_megapixel_threshold", 4)}.get(
+            device_kind, cfg.get("cuda_megapixel_threshold", 8))
+        use_tiling = megapixels > thr
+    use_3ch = cfg["force_3channel"]
+    if megapixels > 16:
+        use_tiling, use_3ch = True, True
+    one = (lambda t: apply_esrgan_3channel(upscaler, t, as_numpy=False)) if use_3ch else \
+          (lambda t: apply_esrgan_12channel(upscaler, t, as_numpy=False))
+    if use_tiling:
+        return process_with_tiling(one, image_rgb, cfg["max_tile_size"], 16, cfg["upscale_factor"], upscaler.device)
+    return one(image_rgb).cpu().numpy()
