@@ -45,6 +45,7 @@ struct Layer {
     std::vector<float> w, b;  // host copies until finalize
     bool has_w = false, has_b = false;
     void* d_w = nullptr;
+    void* d_ww = nullptr;   // Winograd-transformed weights (f32 Winograd contexts)
     float* d_b = nullptr;
 };
 
@@ -52,6 +53,7 @@ struct Layer {
 
 struct nesr_ctx {
     int device = 0, cin0 = 3, unshuffle = 0, nf = 64, nb = 23, gc = 32, nout = 3, dtype = 0;
+    bool winograd = false;   // f32 feature-map convs by Winograd F(2x2,3x3) (NESR_DTYPE_F32_WINOGRAD)
     int kgroup = 8;  // K-group of the conv kernel: cin padding granule
     std::vector<Layer> layers;
     std::unordered_map<std::string, int> index;
@@ -125,8 +127,14 @@ int ensure_ws(nesr_ctx* c, size_t bytes) {
     return NESR_OK;
 }
 
-hipError_t launch_conv(const nesr_ctx* c, const ConvArgs& a, hipStream_t s) {
-    return c->dtype == NESR_DTYPE_BF16 ? launch_conv3x3_bf16(a, s) : launch_conv3x3_f32(a, s);
+hipError_t launch_conv(const nesr_ctx* c, const ConvArgs& a, hipStream_t s, const Layer* L = nullptr) {
+    if (c->dtype == NESR_DTYPE_BF16) return launch_conv3x3_bf16(a, s);
+    if (c->winograd && L && L->d_ww && !a.out_nchw && !a.out_u8) {
+        ConvArgs w = a;
+        w.w = L->d_ww;
+        return launch_conv3x3_wino_f32(w, s);
+    }
+    return launch_conv3x3_f32(a, s);
 }
 
 ConvArgs base_args(const nesr_ctx* c, const Layer& L, int N, int h, int w) {
@@ -198,7 +206,7 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
         a.in = ws + L.in; a.in_map = m_in;
         a.out = ws + L.a; a.out_map = m_t; a.out_coff = 0;
         a.out2 = ws + L.f; a.out2_map = m_f;
-        HIP_TRY(launch_conv(c, a, s));
+        HIP_TRY(launch_conv(c, a, s, &c->layers[0]));
     }
 
     // trunk: 23 x RRDB.  Buffers P,Q,R hold x0|x1|x2|x3|x4 of RDB1,2,3; RDB3's conv5 applies both
@@ -246,7 +254,7 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
                     a.in = cur; a.in_map = m_t;
                     a.out = cur; a.out_map = m_t; a.out_coff = nf + k * gc;
                     a.lrelu = 1;
-                    HIP_TRY(launch_conv(c, a, s));
+                    HIP_TRY(launch_conv(c, a, s, &Ly));
                     if (c->timing) c->timed_flops += conv_flops(Ly, px);
                 }
                 const Layer& L5 = c->layers[layer_id(c, b, r, 4)];
@@ -260,7 +268,7 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
                     a.res2 = buf[0]; a.res2_map = m_t; a.s2 = 0.2f;
                 }
                 a.out_map = m_t; a.out_coff = 0;
-                HIP_TRY(launch_conv(c, a, s));
+                HIP_TRY(launch_conv(c, a, s, &L5));
                 if (c->timing) c->timed_flops += conv_flops(L5, px);
             }
         }
@@ -278,28 +286,28 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
         a.in = buf[0]; a.in_map = m_t;
         a.out = ws + L.f; a.out_map = m_f;
         a.res1 = ws + L.f; a.res1_map = m_f; a.s1 = 1.0f;
-        HIP_TRY(launch_conv(c, a, s));
+        HIP_TRY(launch_conv(c, a, s, &c->layers[tail]));
     }
     // lrelu(conv_up1(nearest2x(feat)))
     {
         ConvArgs a = base_args(c, c->layers[tail + 1], N, 2 * h, 2 * w);
         a.in = ws + L.f; a.in_map = m_f; a.in_h = h; a.in_w = w; a.up = 1;
         a.out = ws + L.u1; a.out_map = m_u1; a.lrelu = 1;
-        HIP_TRY(launch_conv(c, a, s));
+        HIP_TRY(launch_conv(c, a, s, &c->layers[tail + 1]));
     }
     // lrelu(conv_up2(nearest2x(feat)))
     {
         ConvArgs a = base_args(c, c->layers[tail + 2], N, 4 * h, 4 * w);
         a.in = ws + L.u1; a.in_map = m_u1; a.in_h = 2 * h; a.in_w = 2 * w; a.up = 1;
         a.out = ws + L.u2; a.out_map = m_u2; a.lrelu = 1;
-        HIP_TRY(launch_conv(c, a, s));
+        HIP_TRY(launch_conv(c, a, s, &c->layers[tail + 2]));
     }
     // lrelu(conv_hr(feat))
     {
         ConvArgs a = base_args(c, c->layers[tail + 3], N, 4 * h, 4 * w);
         a.in = ws + L.u2; a.in_map = m_u2;
         a.out = ws + L.u3; a.out_map = m_u2; a.lrelu = 1;
-        HIP_TRY(launch_conv(c, a, s));
+        HIP_TRY(launch_conv(c, a, s, &c->layers[tail + 3]));
     }
     // conv_last -> planar f32 NCHW, or clamped + quantised u8 HWC
     {
@@ -334,7 +342,8 @@ int nesr_create(nesr_ctx** out, int device_id, int conv_first_in_ch, int unshuff
     if (num_feat != 32 && num_feat != 64) return fail(NESR_ERR_ARG, "num_feat must be 32 or 64 (reference uses 64)");
     if (num_grow_ch != 32) return fail(NESR_ERR_ARG, "num_grow_ch must be 32 (reference uses 32)");
     if (num_block < 0 || num_out_ch <= 0 || num_out_ch > 32) return fail(NESR_ERR_ARG, "bad num_block / num_out_ch");
-    if (dtype != NESR_DTYPE_F32 && dtype != NESR_DTYPE_BF16) return fail(NESR_ERR_ARG, "dtype must be 0 (f32) or 1 (bf16)");
+    if (dtype != NESR_DTYPE_F32 && dtype != NESR_DTYPE_BF16 && dtype != NESR_DTYPE_F32_WINOGRAD)
+        return fail(NESR_ERR_ARG, "dtype must be 0 (f32), 1 (bf16) or 2 (f32, Winograd)");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device_id < 0 || device_id >= ndev) return fail(NESR_ERR_ARG, "no such device " + std::to_string(device_id));
@@ -346,6 +355,11 @@ int nesr_create(nesr_ctx** out, int device_id, int conv_first_in_ch, int unshuff
     c->nb = num_block;
     c->gc = num_grow_ch;
     c->nout = num_out_ch;
+    c->winograd = dtype == NESR_DTYPE_F32_WINOGRAD;
+    if (const char* e = getenv("NESR_F32_ALGO")) {   // override for A/B timing: direct | winograd
+        if (dtype != NESR_DTYPE_BF16) c->winograd = e[0] == 'w';
+    }
+    if (dtype == NESR_DTYPE_F32_WINOGRAD) dtype = NESR_DTYPE_F32;
     c->dtype = dtype;
     c->kgroup = dtype == NESR_DTYPE_BF16 ? 16 : 8;
     if (const char* e = getenv("NESR_TRUNK")) c->trunk_mode = e[0] == 'l' ? 1 : (e[0] == 'p' ? 2 : 0);
@@ -415,7 +429,8 @@ int nesr_finalize_weights(nesr_ctx* c) {
     HIP_TRY(hipSetDevice(c->device));
     const bool bf = c->dtype == NESR_DTYPE_BF16;
     size_t total = 256;   // leading zero page
-    std::vector<size_t> woff(c->layers.size()), boff(c->layers.size());
+    std::vector<size_t> woff(c->layers.size()), boff(c->layers.size()), wwoff(c->layers.size(), 0);
+    const size_t last = c->layers.size() - 1;   // conv_last keeps the direct kernel (planar / u8 epilogue)
     for (size_t i = 0; i < c->layers.size(); ++i) {
         const Layer& L = c->layers[i];
         const size_t we = bf ? packed_weight_elems_bf16(L.cin_p, L.cout_p) : packed_weight_elems_f32(L.cin_p, L.cout_p);
@@ -423,6 +438,10 @@ int nesr_finalize_weights(nesr_ctx* c) {
         total = align_up(total + we * (bf ? 2 : 4), 256);
         boff[i] = total;
         total = align_up(total + (size_t)L.cout_p * 4, 256);
+        if (c->winograd && i != last) {
+            wwoff[i] = total;
+            total = align_up(total + packed_weight_elems_wino_f32(L.cin_p, L.cout_p) * 4, 256);
+        }
     }
     std::vector<char> host(total, 0);
     for (size_t i = 0; i < c->layers.size(); ++i) {
@@ -432,6 +451,7 @@ int nesr_finalize_weights(nesr_ctx* c) {
         else
             pack_weights_f32(L.w.data(), L.cout, L.cin, L.cin_p, L.cout_p, reinterpret_cast<float*>(host.data() + woff[i]));
         std::memcpy(host.data() + boff[i], L.b.data(), (size_t)L.cout * 4);
+        if (wwoff[i]) pack_weights_wino_f32(L.w.data(), L.cout, L.cin, L.cin_p, L.cout_p, reinterpret_cast<float*>(host.data() + wwoff[i]));
     }
     if (c->d_weights) {
         HIP_TRY(hipDeviceSynchronize());
@@ -445,6 +465,7 @@ int nesr_finalize_weights(nesr_ctx* c) {
     for (size_t i = 0; i < c->layers.size(); ++i) {
         c->layers[i].d_w = c->d_weights + woff[i];
         c->layers[i].d_b = reinterpret_cast<float*>(c->d_weights + boff[i]);
+        c->layers[i].d_ww = wwoff[i] ? c->d_weights + wwoff[i] : nullptr;
     }
     // layer table of the persistent trunk kernel (same wiring as the per-layer loop in run_forward)
     {
@@ -607,7 +628,8 @@ int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, in
                  const float* b_host, int Cout, int lrelu, int upsample, void* y_dev, void* stream) {
     if (!x_dev || !w_host || !b_host || !y_dev) return fail(NESR_ERR_ARG, "null argument");
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout > 64) return fail(NESR_ERR_ARG, "bad shape (Cout <= 64)");
-    if (dtype != NESR_DTYPE_F32 && dtype != NESR_DTYPE_BF16) return fail(NESR_ERR_ARG, "bad dtype");
+    if (dtype != NESR_DTYPE_F32 && dtype != NESR_DTYPE_BF16 && dtype != NESR_DTYPE_F32_WINOGRAD) return fail(NESR_ERR_ARG, "bad dtype");
+    const bool wino = dtype == NESR_DTYPE_F32_WINOGRAD;
     HIP_TRY(hipSetDevice(device_id));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool bf = dtype == NESR_DTYPE_BF16;
@@ -615,10 +637,13 @@ int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, in
     const int cin_p = round_up(Cin, bf ? 16 : 8), cout_p = round_up(Cout, 32);
     const int up = upsample ? 1 : 0;
     const int ho = H << up, wo = W << up;
-    const size_t we = bf ? packed_weight_elems_bf16(cin_p, cout_p) : packed_weight_elems_f32(cin_p, cout_p);
+    const size_t we = bf ? packed_weight_elems_bf16(cin_p, cout_p)
+                         : (wino ? packed_weight_elems_wino_f32(cin_p, cout_p) : packed_weight_elems_f32(cin_p, cout_p));
     std::vector<char> hw(we * es);
     if (bf)
         pack_weights_bf16(w_host, Cout, Cin, cin_p, cout_p, reinterpret_cast<uint16_t*>(hw.data()));
+    else if (wino)
+        pack_weights_wino_f32(w_host, Cout, Cin, cin_p, cout_p, reinterpret_cast<float*>(hw.data()));
     else
         pack_weights_f32(w_host, Cout, Cin, cin_p, cout_p, reinterpret_cast<float*>(hw.data()));
     std::vector<float> hb(cout_p, 0.f);
@@ -647,7 +672,7 @@ int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, in
     a.out = d_out; a.out_map = mo; a.out_coff = 0;
     a.lrelu = lrelu ? 1 : 0; a.s1 = a.s2 = 1.f;
     a.zeros = d_zero;
-    HIP_TRY(bf ? launch_conv3x3_bf16(a, s) : launch_conv3x3_f32(a, s));
+    HIP_TRY(bf ? launch_conv3x3_bf16(a, s) : (wino ? launch_conv3x3_wino_f32(a, s) : launch_conv3x3_f32(a, s)));
     HIP_TRY(launch_nhwc_to_nchw(d_out, bf, mo, N, Cout, ho, wo, static_cast<float*>(y_dev), s));
     HIP_TRY(hipStreamSynchronize(s));
     (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_zero);

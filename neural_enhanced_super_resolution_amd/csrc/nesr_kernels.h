@@ -62,6 +62,12 @@ hipError_t launch_conv3x3_f32(const ConvArgs& a, hipStream_t s);
 size_t packed_weight_elems_f32(int cin_p, int coutp);
 void pack_weights_f32(const float* oihw, int cout, int cin, int cin_p, int coutp, float* dst);
 
+// f32 Winograd F(2x2,3x3) path: v_mfma_f32_16x16x4_f32, 2.25x less matrix work (conv3x3_wino_f32.hip);
+// feature-map outputs only (conv_last keeps the direct kernel)
+hipError_t launch_conv3x3_wino_f32(const ConvArgs& a, hipStream_t s);
+size_t packed_weight_elems_wino_f32(int cin_p, int coutp);
+void pack_weights_wino_f32(const float* oihw, int cout, int cin, int cin_p, int coutp, float* dst);
+
 // bf16 path: v_mfma_f32_32x32x16_bf16 implicit GEMM (conv3x3_bf16.hip)
 hipError_t launch_conv3x3_bf16(const ConvArgs& a, hipStream_t s);       // picks the variant by frame size
 hipError_t launch_conv3x3_bf16_xl(const ConvArgs& a, hipStream_t s);    // conv3x3_bf16.hip: 32x32-px tiles, 3-deep LDS-DMA ring

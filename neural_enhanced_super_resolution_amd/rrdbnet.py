@@ -145,6 +145,8 @@ class RRDBNet(nn.Module):
     def _dtype_code(self):
         if self.compute_dtype in ("f32", "fp32", torch.float32):
             return _lib.DTYPE_F32
+        if self.compute_dtype in ("f32-winograd", "f32w", "winograd"):
+            return _lib.DTYPE_F32_WINOGRAD
         if self.compute_dtype in ("bf16", torch.bfloat16, "half", torch.float16):
             return _lib.DTYPE_BF16
         raise ValueError(f"compute_dtype {self.compute_dtype!r}: expected 'f32' or 'bf16'")
@@ -280,7 +282,8 @@ def conv3x3(x, weight, bias, lrelu=False, upsample=False, dtype="f32"):
     index = x.device.index if x.device.index is not None else torch.cuda.current_device()
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        _lib.check(lib.nesr_conv3x3(index, _lib.DTYPE_BF16 if dtype == "bf16" else _lib.DTYPE_F32,
+        code = {"bf16": _lib.DTYPE_BF16, "f32-winograd": _lib.DTYPE_F32_WINOGRAD}.get(dtype, _lib.DTYPE_F32)
+        _lib.check(lib.nesr_conv3x3(index, code,
                                     ctypes.c_void_p(x.data_ptr()), n, cin, h, w, ctypes.c_void_p(wt.data_ptr()),
                                     ctypes.c_void_p(bs.data_ptr()), cout, 1 if lrelu else 0, up,
                                     ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(stream)), "nesr_conv3x3")

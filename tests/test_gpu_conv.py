@@ -115,3 +115,35 @@ def test_conv3x3_bf16_xl_upsample(cuda_device):
     ref = F.conv2d(F.interpolate(x.bfloat16().float(), scale_factor=2, mode="nearest"), wgt.bfloat16().float(), b, padding=1)
     got = conv3x3(x.to(cuda_device), wgt, b, upsample=True, dtype="bf16").cpu()
     assert (got - ref).abs().max().item() < 2 ** -7 * max(1.0, ref.abs().max().item())
+
+
+WINO_TOL = 2e-5   # relative to max|ref|: Winograd's transforms add a few ulps to the direct form
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 64), (64, 32), (96, 32), (128, 32), (160, 32), (192, 64), (64, 64)])
+@pytest.mark.parametrize("hw", [(24, 40), (9, 17), (33, 47)])
+def test_conv3x3_f32_winograd_matches_torch(cuda_device, cin, cout, hw):
+    from neural_enhanced_super_resolution_amd import conv3x3
+    x, w, b = _case(cin, cout, hw[0], hw[1], seed=cin * 7 + cout + hw[0], n=2)
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2)
+    got = conv3x3(x.to(cuda_device), w, b, lrelu=True, dtype="f32-winograd").cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < WINO_TOL * max(1.0, ref.abs().max().item())
+
+
+def test_conv3x3_f32_winograd_one_hot_taps_and_upsample(cuda_device):
+    from neural_enhanced_super_resolution_amd import conv3x3
+    cin, cout = 16, 32
+    x = (torch.arange(cin * 10 * 12, dtype=torch.float32).reshape(1, cin, 10, 12) * 3) % 127
+    for tap in range(9):
+        w = torch.zeros(cout, cin, 3, 3)
+        for o in range(cout):
+            w[o, (o * 5 + tap) % cin, tap // 3, tap % 3] = 1.0
+        b = torch.arange(cout, dtype=torch.float32)
+        ref = F.conv2d(x, w, b, padding=1)
+        got = conv3x3(x.to(cuda_device), w, b, dtype="f32-winograd").cpu()
+        assert (got - ref).abs().max().item() < 1e-3, f"tap {tap}"      # small integers: transforms are exact up to halves
+    xs, ws, bs = _case(64, 64, 13, 21, seed=5)
+    ref = F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), ws, bs, padding=1)
+    got = conv3x3(xs.to(cuda_device), ws, bs, upsample=True, dtype="f32-winograd").cpu()
+    assert (got - ref).abs().max().item() < WINO_TOL * max(1.0, ref.abs().max().item())

@@ -136,3 +136,23 @@ def test_persistent_trunk_equals_per_layer_launches(cuda_device, monkeypatch, sh
     for _ in range(3):                      # repeat: hand-off races would show up as run-to-run differences
         assert torch.equal(a(x), ya)
     a.check_status()
+
+
+def test_winograd_full_depth_within_tolerance(cuda_device):
+    """f32 Winograd F(2x2,3x3) for the feature-map convs: full 23-block x2plus net vs the oracle."""
+    ours, ref = _pair(3, 2, num_block=23, seed=0, compute_dtype="f32-winograd")
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(11))
+    want = ref(x)
+    got = ours(x.to(cuda_device)).cpu()
+    err = (got - want).abs().max().item()
+    print("winograd full-depth x2plus 64x64 max abs err", err)
+    assert err < TOL_F32, err
+    assert err < 1e-4, err
+
+
+@pytest.mark.parametrize("num_in_ch,scale", MODES)
+def test_winograd_mininet_modes(cuda_device, num_in_ch, scale):
+    ours, ref = _pair(num_in_ch, scale, num_block=2, seed=3, compute_dtype="f32-winograd")
+    x = torch.rand(2, num_in_ch, 34, 46, generator=torch.Generator().manual_seed(7))
+    err = (ours(x.to(cuda_device)).cpu() - ref(x)).abs().max().item()
+    assert err < 1e-4, err
