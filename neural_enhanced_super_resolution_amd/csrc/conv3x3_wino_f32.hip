@@ -186,26 +186,36 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
             V[4 * r + 3] = t0[r][1] - t0[r][3];
         }
         // 16x16x4 f32 MFMA: 32-cycle issue, 40-cycle dependent latency -> the two k-steps of one
-        // accumulator are separated by an MFMA on another accumulator
+        // accumulator are separated by an MFMA on another accumulator.  Groups of 4 MFMAs; the
+        // weight fragments of the next group are read while the current group runs (pinned with
+        // sched_barrier: left alone hipcc sinks each ds_read to just before its s_waitcnt and
+        // re-pairs the dependent MFMAs).
         auto U = [&](int p, int t) -> f32x2 { return *reinterpret_cast<const f32x2*>(st + w0 + (p * 2 * NT + t) * 512); };
-        if constexpr (NT == 2) {
+        constexpr int GROUPS = NT == 2 ? 16 : 8;          // NT=2: one position x 2 cout groups; NT=1: two positions
+        f32x2 ua[2], ub[2];
+        if constexpr (NT == 2) { ua[0] = U(0, 0); ub[0] = U(0, 1); } else { ua[0] = U(0, 0); ub[0] = U(1, 0); }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                const f32x2 u0 = U(p, 0), u1 = U(p, 1);
-                acc[0][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u0[0], V[p][0], acc[0][p], 0, 0, 0);
-                acc[1][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u1[0], V[p][0], acc[1][p], 0, 0, 0);
-                acc[0][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u0[1], V[p][1], acc[0][p], 0, 0, 0);
-                acc[1][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u1[1], V[p][1], acc[1][p], 0, 0, 0);
+        for (int g = 0; g < GROUPS; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+            if (g + 1 < GROUPS) {
+                if constexpr (NT == 2) { ua[nxt] = U(g + 1, 0); ub[nxt] = U(g + 1, 1); }
+                else { ua[nxt] = U(2 * g + 2, 0); ub[nxt] = U(2 * g + 3, 0); }
             }
-        } else {
-#pragma unroll
-            for (int p = 0; p < 16; p += 2) {
-                const f32x2 u0 = U(p, 0), u1 = U(p + 1, 0);
-                acc[0][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u0[0], V[p][0], acc[0][p], 0, 0, 0);
-                acc[0][p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u1[0], V[p + 1][0], acc[0][p + 1], 0, 0, 0);
-                acc[0][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(u0[1], V[p][1], acc[0][p], 0, 0, 0);
-                acc[0][p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(u1[1], V[p + 1][1], acc[0][p + 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NT == 2) {
+                acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[cur][0], V[g][0], acc[0][g], 0, 0, 0);
+                acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[cur][0], V[g][0], acc[1][g], 0, 0, 0);
+                acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[cur][1], V[g][1], acc[0][g], 0, 0, 0);
+                acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[cur][1], V[g][1], acc[1][g], 0, 0, 0);
+            } else {
+                const int p = 2 * g;
+                acc[0][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[cur][0], V[p][0], acc[0][p], 0, 0, 0);
+                acc[0][p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[cur][0], V[p + 1][0], acc[0][p + 1], 0, 0, 0);
+                acc[0][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[cur][1], V[p][1], acc[0][p], 0, 0, 0);
+                acc[0][p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[cur][1], V[p + 1][1], acc[0][p + 1], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         store_chunk(s_fill);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's weight DMA (issued a whole chunk ago) has landed
