@@ -145,53 +145,88 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
 #pragma unroll
         for (int p = 0; p < 16; ++p) acc[t][p] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // bias is fetched now so its latency hides under the K loop
+    f32x4 bias_r[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bias_r[t] = *reinterpret_cast<const f32x4*>(a.bias + 16 * (NT * cgw + t) + 4 * kq);
+
     const int nchunks = a.cin / 8;
     // LDS ring of STAGES slots, STAGES-1 chunks staged ahead (3 slots for Cout=32; Cout=64 has room
     // for 2 per workgroup at two workgroups per CU)
+    {   // all prologue chunks in flight together (one memory round trip)
+        f32x4 pq[STAGES - 1][RI];
 #pragma unroll
-    for (int i = 0; i < STAGES - 1; ++i) {
-        const int ci = i < nchunks ? i : nchunks - 1;
-        dma_weights(ci, i);
-        load_chunk(ci);
-        store_chunk(i);
+        for (int i = 0; i < STAGES - 1; ++i) {
+            const int ci = i < nchunks ? i : nchunks - 1;
+            dma_weights(ci, i);
+            load_chunk(ci);
+#pragma unroll
+            for (int r = 0; r < RI; ++r) pq[i][r] = pv[r];
+        }
+#pragma unroll
+        for (int i = 0; i < STAGES - 1; ++i) {
+#pragma unroll
+            for (int r = 0; r < RI; ++r) pv[r] = pq[i][r];
+            store_chunk(i);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the prologue's weight DMAs have landed
     __syncthreads();
-    int s_cur = 0, s_fill = STAGES - 1;
+
+    // input transform helpers: V = B^T d B of this lane's tile for its two channels (f32x2 = both channels)
+    auto read_row = [&](const char* st, int r, f32x2 (&d)[4][4]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[r][q] = *reinterpret_cast<const f32x2*>(st + patch0 + (r * PW + q) * 8);
+    };
+    auto bt_cols = [&](const f32x2 (&d)[4][4], f32x2 (&t0)[4][4], int q) {   // column q of B^T d
+        t0[0][q] = d[0][q] - d[2][q];
+        t0[1][q] = d[1][q] + d[2][q];
+        t0[2][q] = d[2][q] - d[1][q];
+        t0[3][q] = d[1][q] - d[3][q];
+    };
+    auto b_row = [&](const f32x2 (&t0)[4][4], f32x2 (&V)[16], int r) {       // row r of (B^T d) B
+        V[4 * r + 0] = t0[r][0] - t0[r][2];
+        V[4 * r + 1] = t0[r][1] + t0[r][2];
+        V[4 * r + 2] = t0[r][2] - t0[r][1];
+        V[4 * r + 3] = t0[r][1] - t0[r][3];
+    };
+    // 16x16x4 f32 MFMA: 32-cycle issue, 40-cycle dependent latency -> the two k-steps of one accumulator
+    // are separated by an MFMA on another accumulator.  Groups of 4 MFMAs; the weight fragments of the
+    // next group are read while the current group runs, and (3-slot ring: the next chunk is already
+    // visible) the NEXT chunk's patch reads and input transform are sliced into the groups as well, so
+    // the VALU work runs beside the MFMA pipe instead of in front of it.  Everything is pinned with
+    // sched_barrier: left alone hipcc sinks each ds_read to just before its s_waitcnt and re-pairs the
+    // dependent MFMAs.
+    constexpr int GROUPS = NT == 2 ? 16 : 8;   // NT=2: one position x 2 cout groups; NT=1: two positions
+    constexpr bool PIPE = STAGES == 3;
+
+    int s_cur = 0, s_nxt = 1 % STAGES, s_fill = STAGES - 1;
+    f32x2 V[16];
+    if constexpr (PIPE) {
+        f32x2 d[4][4], t0[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) read_row(smem, r, d);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bt_cols(d, t0, q);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b_row(t0, V, r);
+    }
     for (int c = 0; c < nchunks; ++c) {
         const int cn = c + STAGES - 1 < nchunks ? c + STAGES - 1 : nchunks - 1;
         dma_weights(cn, s_fill);    // slot s_fill was last read in iteration c-1 (barrier passed)
         load_chunk(cn);
         const char* st = smem + s_cur * STAGE_BYTES;
-        // input transform V = B^T d B of this lane's tile for its two channels
-        f32x2 d[4][4];
+        const char* sn = smem + s_nxt * STAGE_BYTES;
+        f32x2 dn[4][4], tn[4][4], Vn[16];
+        if constexpr (!PIPE) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r) read_row(st, r, dn);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) d[r][q] = *reinterpret_cast<const f32x2*>(st + patch0 + (r * PW + q) * 8);
-        f32x2 t0[4][4];   // B^T d
+            for (int q = 0; q < 4; ++q) bt_cols(dn, tn, q);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            t0[0][q] = d[0][q] - d[2][q];
-            t0[1][q] = d[1][q] + d[2][q];
-            t0[2][q] = d[2][q] - d[1][q];
-            t0[3][q] = d[1][q] - d[3][q];
+            for (int r = 0; r < 4; ++r) b_row(tn, V, r);
         }
-        f32x2 V[16];      // (B^T d) B, position p = 4*row + col
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            V[4 * r + 0] = t0[r][0] - t0[r][2];
-            V[4 * r + 1] = t0[r][1] + t0[r][2];
-            V[4 * r + 2] = t0[r][2] - t0[r][1];
-            V[4 * r + 3] = t0[r][1] - t0[r][3];
-        }
-        // 16x16x4 f32 MFMA: 32-cycle issue, 40-cycle dependent latency -> the two k-steps of one
-        // accumulator are separated by an MFMA on another accumulator.  Groups of 4 MFMAs; the
-        // weight fragments of the next group are read while the current group runs (pinned with
-        // sched_barrier: left alone hipcc sinks each ds_read to just before its s_waitcnt and
-        // re-pairs the dependent MFMAs).
         auto U = [&](int p, int t) -> f32x2 { return *reinterpret_cast<const f32x2*>(st + w0 + (p * 2 * NT + t) * 512); };
-        constexpr int GROUPS = NT == 2 ? 16 : 8;          // NT=2: one position x 2 cout groups; NT=1: two positions
         f32x2 ua[2], ub[2];
         if constexpr (NT == 2) { ua[0] = U(0, 0); ub[0] = U(0, 1); } else { ua[0] = U(0, 0); ub[0] = U(1, 0); }
         __builtin_amdgcn_sched_barrier(0);
@@ -201,6 +236,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
             if (g + 1 < GROUPS) {
                 if constexpr (NT == 2) { ua[nxt] = U(g + 1, 0); ub[nxt] = U(g + 1, 1); }
                 else { ua[nxt] = U(2 * g + 2, 0); ub[nxt] = U(2 * g + 3, 0); }
+            }
+            if constexpr (PIPE) {   // a slice of the next chunk's input transform (GROUPS == 8 here)
+                if (g < 4) read_row(sn, g, dn);
+                else if (g == 4) { bt_cols(dn, tn, 0); bt_cols(dn, tn, 1); }
+                else if (g == 5) { bt_cols(dn, tn, 2); bt_cols(dn, tn, 3); }
+                else if (g == 6) { b_row(tn, Vn, 0); b_row(tn, Vn, 1); }
+                else { b_row(tn, Vn, 2); b_row(tn, Vn, 3); }
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (NT == 2) {
@@ -217,10 +259,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int p = 0; p < 16; ++p) V[p] = Vn[p];
+        }
         store_chunk(s_fill);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's weight DMA (issued a whole chunk ago) has landed
         __syncthreads();
         s_cur = s_cur == STAGES - 1 ? 0 : s_cur + 1;
+        s_nxt = s_nxt == STAGES - 1 ? 0 : s_nxt + 1;
         s_fill = s_fill == STAGES - 1 ? 0 : s_fill + 1;
     }
 
@@ -233,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int co = 16 * (NT * cgw + t) + 4 * kq;
-        const f32x4 bias = *reinterpret_cast<const f32x4*>(a.bias + co);
+        const f32x4 bias = bias_r[t];
         // A^T M A with A^T = [1 1 1 0; 0 1 -1 -1]; positions p = 4*row + col
         f32x4 m0[4], m1[4];   // rows of A^T M (2 x 4)
 #pragma unroll

@@ -77,7 +77,9 @@ class RRDBNet(nn.Module):
     """Networks consisting of Residual in Residual Dense Blocks (ESRGAN / Real-ESRGAN generator).
 
     Args mirror upstream: num_in_ch, num_out_ch, scale=4, num_feat=64, num_block=23, num_grow_ch=32.
-    Extra keyword ``compute_dtype``: "f32" (default; the reference's half=False) or "bf16".
+    Extra keyword ``compute_dtype``: "f32" (default; the reference's half=False: f32 storage and f32
+    matrix-core arithmetic, 3x3 convs by Winograd F(2x2,3x3)), "f32-direct" (f32, direct implicit GEMM:
+    bitwise a k-ordered fmaf chain) or "bf16".
     """
 
     def __init__(self, num_in_ch, num_out_ch, scale=4, num_feat=64, num_block=23, num_grow_ch=32,
@@ -143,10 +145,10 @@ class RRDBNet(nn.Module):
             pass
 
     def _dtype_code(self):
-        if self.compute_dtype in ("f32", "fp32", torch.float32):
-            return _lib.DTYPE_F32
-        if self.compute_dtype in ("f32-winograd", "f32w", "winograd"):
-            return _lib.DTYPE_F32_WINOGRAD
+        if self.compute_dtype in ("f32", "fp32", torch.float32, "f32-winograd", "f32w", "winograd"):
+            return _lib.DTYPE_F32_WINOGRAD      # default f32 algorithm: Winograd F(2x2,3x3) for the feature-map convs
+        if self.compute_dtype in ("f32-direct", "direct"):
+            return _lib.DTYPE_F32               # direct implicit GEMM everywhere (bitwise a k-ordered fmaf chain)
         if self.compute_dtype in ("bf16", torch.bfloat16, "half", torch.float16):
             return _lib.DTYPE_BF16
         raise ValueError(f"compute_dtype {self.compute_dtype!r}: expected 'f32' or 'bf16'")
@@ -282,7 +284,8 @@ def conv3x3(x, weight, bias, lrelu=False, upsample=False, dtype="f32"):
     index = x.device.index if x.device.index is not None else torch.cuda.current_device()
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        code = {"bf16": _lib.DTYPE_BF16, "f32-winograd": _lib.DTYPE_F32_WINOGRAD}.get(dtype, _lib.DTYPE_F32)
+        code = {"bf16": _lib.DTYPE_BF16, "f32-winograd": _lib.DTYPE_F32_WINOGRAD, "f32": _lib.DTYPE_F32,
+                "f32-direct": _lib.DTYPE_F32}[dtype]
         _lib.check(lib.nesr_conv3x3(index, code,
                                     ctypes.c_void_p(x.data_ptr()), n, cin, h, w, ctypes.c_void_p(wt.data_ptr()),
                                     ctypes.c_void_p(bs.data_ptr()), cout, 1 if lrelu else 0, up,

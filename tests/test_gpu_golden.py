@@ -149,18 +149,22 @@ def test_linearity_property_at_full_size(cuda_device):
     assert (lhs - rhs).abs().max().item() < 1e-4
 
 
-def test_translation_property_full_net(cuda_device):
-    """Away from borders the network commutes with translation by a whole trunk pixel: shifting
-    the input by 2 px shifts the x2 output by 4 px (exact same arithmetic per pixel -> bit equal)."""
+@pytest.mark.parametrize("algo,shift", [("f32-direct", 2), ("f32", 4)])
+def test_translation_property_full_net(cuda_device, algo, shift):
+    """Away from borders the network commutes with translation: the direct kernel's per-pixel
+    arithmetic is position independent (any whole trunk pixel = 2 input px), the Winograd kernel's
+    depends only on the position inside its 2x2 output tile (2 trunk px = 4 input px).  A shift by that
+    period must reproduce the output bit for bit, shifted by 2x."""
     sd = synthetic_state_dict(seed=3, num_in_ch=3, scale=2, num_block=1)
-    net = RRDBNet(3, 3, scale=2, num_block=1)
+    net = RRDBNet(3, 3, scale=2, num_block=1, compute_dtype=algo)
     net.load_state_dict(sd)
     net.to(cuda_device)
     x = torch.rand(1, 3, 128, 160, generator=torch.Generator().manual_seed(1)).to(cuda_device)
     y0 = net(x)
-    y1 = net(torch.roll(x, shifts=(2, 2), dims=(2, 3)))
+    y1 = net(torch.roll(x, shifts=(shift, shift), dims=(2, 3)))
     m = 88   # > receptive-field radius of the 1-block net at output resolution (17 trunk px * 4 + upsampler convs)
-    assert torch.equal(y1[:, :, m + 4:-m, m + 4:-m], y0[:, :, m:-m - 4, m:-m - 4])
+    o = 2 * shift
+    assert torch.equal(y1[:, :, m + o:-m, m + o:-m], y0[:, :, m:-m - o, m:-m - o])
 
 
 @pytest.mark.parametrize("kw", [dict(tile=32, tile_pad=10, pre_pad=0), dict(tile=32, tile_pad=10, pre_pad=10), dict(tile=0, tile_pad=10, pre_pad=10)])

@@ -32,8 +32,9 @@ MODES = [
 
 @pytest.mark.parametrize("num_in_ch,scale", MODES)
 @pytest.mark.parametrize("hw", [(32, 48), (34, 46)])
-def test_mininet_matches_oracle(cuda_device, num_in_ch, scale, hw):
-    ours, ref = _pair(num_in_ch, scale, num_block=2, seed=3)
+@pytest.mark.parametrize("algo", ["f32", "f32-direct"])
+def test_mininet_matches_oracle(cuda_device, num_in_ch, scale, hw, algo):
+    ours, ref = _pair(num_in_ch, scale, num_block=2, seed=3, compute_dtype=algo)
     x = torch.rand(1, num_in_ch, *hw, generator=torch.Generator().manual_seed(7))
     want = ref(x)
     got = ours(x.to(cuda_device)).cpu()
@@ -43,8 +44,9 @@ def test_mininet_matches_oracle(cuda_device, num_in_ch, scale, hw):
     assert err < 5e-5, f"fp32 path should be ~1e-6 off the oracle at 2 blocks, got {err}"
 
 
-def test_full_depth_x2plus_64(cuda_device):
-    ours, ref = _pair(3, 2, num_block=23, seed=0)
+@pytest.mark.parametrize("algo", ["f32", "f32-direct"])
+def test_full_depth_x2plus_64(cuda_device, algo):
+    ours, ref = _pair(3, 2, num_block=23, seed=0, compute_dtype=algo)
     x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(11))
     want = ref(x)
     got = ours(x.to(cuda_device)).cpu()
@@ -115,7 +117,7 @@ def _model_with_env(monkeypatch, trunk, num_block, seed):
     from neural_enhanced_super_resolution_amd import RRDBNet
     from neural_enhanced_super_resolution_amd.synth import synthetic_state_dict
     monkeypatch.setenv("NESR_TRUNK", trunk)       # read when the HIP context is created
-    net = RRDBNet(3, 3, scale=2, num_block=num_block)
+    net = RRDBNet(3, 3, scale=2, num_block=num_block, compute_dtype="f32-direct")   # the persistent kernel is the direct form
     net.load_state_dict(synthetic_state_dict(seed=seed, num_in_ch=3, scale=2, num_block=num_block))
     return net.to("cuda:0")
 
