@@ -199,6 +199,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
     // dependent MFMAs.
     constexpr int GROUPS = NT == 2 ? 16 : 8;   // NT=2: one position x 2 cout groups; NT=1: two positions
     constexpr bool PIPE = STAGES == 3;
+    // conv_last (cout_real <= 16 real channels, planar / u8 output): the waves of the second
+    // 16-channel group have nothing to compute -- they only help staging and keep the barriers
+    const bool idle = NT == 1 && a.cout_real > 0 && cgw == 1;
 
     int s_cur = 0, s_nxt = 1 % STAGES, s_fill = STAGES - 1;
     f32x2 V[16];
@@ -230,6 +233,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
         f32x2 ua[2], ub[2];
         if constexpr (NT == 2) { ua[0] = U(0, 0); ub[0] = U(0, 1); } else { ua[0] = U(0, 0); ub[0] = U(1, 0); }
         __builtin_amdgcn_sched_barrier(0);
+        if (!idle) {
 #pragma unroll
         for (int g = 0; g < GROUPS; ++g) {
             const int cur = g & 1, nxt = cur ^ 1;
@@ -259,9 +263,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        }
         if constexpr (PIPE) {
+            if (!idle) {
 #pragma unroll
-            for (int p = 0; p < 16; ++p) V[p] = Vn[p];
+                for (int p = 0; p < 16; ++p) V[p] = Vn[p];
+            }
         }
         store_chunk(s_fill);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's weight DMA (issued a whole chunk ago) has landed
@@ -273,6 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
 
     // ---- output transform + fused epilogue.  C/D map of 16x16x4: col = lane&15 (tile), rows 4*(lane>>4)+r
     // (couts); this lane: tile (tr, tc), channels 16*(NT*cgw + t) + 4*kq .. +3.
+    if (idle) return;
     const float* res1 = static_cast<const float*>(a.res1);
     const float* res2 = static_cast<const float*>(a.res2);
     float* out = static_cast<float*>(a.out);
@@ -319,6 +327,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
                 if (valid) {
                     if (out) *reinterpret_cast<f32x4*>(out + at(a.out_map, a.out_coff + co)) = v;
                     if (out2) *reinterpret_cast<f32x4*>(out2 + at(a.out2_map, co)) = v;
+                    if (a.cout_real > 0 && co == 0) {
+                        // conv_last: channels 0..cout_real-1 (<= 4) are this lane's run (cgw = 0, kq = 0)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (q >= a.cout_real) break;
+                            if (a.out_nchw) a.out_nchw[(((size_t)n * a.cout_real + q) * a.h + Y) * a.w_ + X] = v[q];
+                            if (a.out_u8) {
+                                float qv = fminf(fmaxf(v[q], 0.f), 1.f) * 255.0f;
+                                qv = a.u8_round ? rintf(qv) : truncf(qv);
+                                const int ch = a.u8_flip ? (a.cout_real - 1 - q) : q;
+                                a.out_u8[pix * a.cout_real + ch] = (uint8_t)qv;
+                            }
+                        }
+                    }
                 }
             }
     }
@@ -367,7 +389,8 @@ void pack_weights_wino_f32(const float* oihw, int cout, int cin, int cin_p, int 
 }
 
 hipError_t launch_conv3x3_wino_f32(const ConvArgs& a, hipStream_t s) {
-    if (a.cin % 8 || a.out_nchw || a.out_u8) return hipErrorInvalidValue;   // feature-map outputs only
+    if (a.cin % 8) return hipErrorInvalidValue;
+    if ((a.out_nchw || a.out_u8) && (a.coutp != 32 || a.cout_real < 1 || a.cout_real > 4)) return hipErrorInvalidValue;
     if (a.coutp == 64) return launch_wino<2, 2>(a, s);   // 2 x 38.5 KB -> two workgroups per CU
     if (a.coutp == 32) return launch_wino<1, 3>(a, s);   // 3 x 22.1 KB -> two workgroups per CU
     return hipErrorInvalidValue;

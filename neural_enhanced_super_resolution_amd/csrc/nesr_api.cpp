@@ -129,7 +129,7 @@ int ensure_ws(nesr_ctx* c, size_t bytes) {
 
 hipError_t launch_conv(const nesr_ctx* c, const ConvArgs& a, hipStream_t s, const Layer* L = nullptr) {
     if (c->dtype == NESR_DTYPE_BF16) return launch_conv3x3_bf16(a, s);
-    if (c->winograd && L && L->d_ww && !a.out_nchw && !a.out_u8) {
+    if (c->winograd && L && L->d_ww && (!(a.out_nchw || a.out_u8) || (a.cout_real >= 1 && a.cout_real <= 4 && a.coutp == 32))) {
         ConvArgs w = a;
         w.w = L->d_ww;
         return launch_conv3x3_wino_f32(w, s);
@@ -318,7 +318,7 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
         a.out_u8 = y_u8;
         a.u8_flip = flip;
         a.u8_round = round_mode;
-        HIP_TRY(launch_conv(c, a, s));
+        HIP_TRY(launch_conv(c, a, s, &c->layers[tail + 4]));
     }
     return NESR_OK;
 }
@@ -430,7 +430,7 @@ int nesr_finalize_weights(nesr_ctx* c) {
     const bool bf = c->dtype == NESR_DTYPE_BF16;
     size_t total = 256;   // leading zero page
     std::vector<size_t> woff(c->layers.size()), boff(c->layers.size()), wwoff(c->layers.size(), 0);
-    const size_t last = c->layers.size() - 1;   // conv_last keeps the direct kernel (planar / u8 epilogue)
+    const size_t last = c->layers.size() - 1;
     for (size_t i = 0; i < c->layers.size(); ++i) {
         const Layer& L = c->layers[i];
         const size_t we = bf ? packed_weight_elems_bf16(L.cin_p, L.cout_p) : packed_weight_elems_f32(L.cin_p, L.cout_p);
@@ -438,7 +438,8 @@ int nesr_finalize_weights(nesr_ctx* c) {
         total = align_up(total + we * (bf ? 2 : 4), 256);
         boff[i] = total;
         total = align_up(total + (size_t)L.cout_p * 4, 256);
-        if (c->winograd && i != last) {
+        (void)last;
+        if (c->winograd) {
             wwoff[i] = total;
             total = align_up(total + packed_weight_elems_wino_f32(L.cin_p, L.cout_p) * 4, 256);
         }
