@@ -204,6 +204,9 @@ def main():
         # matrix cores execute algorithmic/2.25 FLOPs; `achieved`/`frac` use the ALGORITHMIC (direct-conv)
         # FLOPs as the contract asks, `executed_frac` is the matrix-core utilisation of what actually runs.
         wino = dtype == "f32" and os.environ.get("NESR_F32_ALGO", "w")[0] == "w"
+        if wl["tile"] > 0 and getattr(up, "tile_streams", 1) > 1:
+            result["roofline_note"] = ("tile groups run on concurrent streams: the per-stream HIP-event brackets overlap, "
+                                       "so `achieved` is a lower bound; tflops_whole_net is the wall-clock figure")
         result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                               "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.workload),
                               "algorithm": "winograd F(2x2,3x3), f32 MFMA 16x16x4" if wino else "direct implicit GEMM",

@@ -69,6 +69,7 @@ class RealESRGANer:
         self.mod_scale = None
         self.half = half
         self.tile_batch = 24  # upper bound on equal-shaped tiles per forward call (1 = upstream's serial loop)
+        self.tile_streams = 3 # HIP streams (context replicas) the shape groups of one frame are spread over
 
         if gpu_id:
             self.device = torch.device(f"cuda:{gpu_id}" if torch.cuda.is_available() else "cpu") if device is None else device
@@ -179,32 +180,65 @@ class RealESRGANer:
             nb = self.model.preferred_batch(self.device, th, tw, nb)
         return nb
 
+    def run_tiles(self, img, tiles, sink):
+        """Evaluates the network on windows of `img` ([1,C,H,W] on self.device).  `tiles` is a list of
+        (y0, y1, x0, x1, payload); `sink(payload, out)` receives each window's output [1,C,h*s,w*s] (a view
+        valid on the current stream).  Equal-shaped windows are batched (batch_for); on the HIP backend
+        the shape groups are spread over `tile_streams` streams with their own context replicas, so the
+        small edge-tile groups -- whose 351 launches are latency-bound -- overlap the large ones.
+        Values do not depend on batching or stream assignment."""
+        groups = {}
+        for t in tiles:
+            groups.setdefault((t[1] - t[0], t[3] - t[2]), []).append(t)
+        order = sorted(groups.items(), key=lambda kv: -kv[0][0] * kv[0][1] * len(kv[1]))
+        hip = isinstance(self.model, RRDBNet) and img.device.type == "cuda"
+        nstreams = max(1, int(self.tile_streams)) if hip and len(order) > 1 else 1
+
+        def run_group(shape, ts, slot):
+            nb = self.batch_for(shape[0], shape[1], len(ts)) if img.shape[0] == 1 else 1
+            for i in range(0, len(ts), nb):
+                chunk = ts[i:i + nb]
+                if len(chunk) == 1:
+                    inp = img[:, :, chunk[0][0]:chunk[0][1], chunk[0][2]:chunk[0][3]]
+                else:
+                    inp = torch.cat([img[:, :, t[0]:t[1], t[2]:t[3]] for t in chunk], 0)
+                with torch.no_grad():
+                    out = self.model(inp, slot=slot) if hip else self.model(inp)
+                for j, t in enumerate(chunk):
+                    sink(t[4], out[j:j + 1] if len(chunk) > 1 else out)
+
+        if nstreams == 1:
+            for shape, ts in order:
+                run_group(shape, ts, 0)
+            return
+        main = torch.cuda.current_stream(img.device)
+        if not hasattr(self, "_side_streams") or len(self._side_streams) < nstreams - 1:
+            self._side_streams = [torch.cuda.Stream(device=img.device) for _ in range(nstreams - 1)]
+        streams = [main] + self._side_streams[:nstreams - 1]
+        for s in streams[1:]:
+            s.wait_stream(main)                       # img / the output canvas were produced on the main stream
+        load = [0] * nstreams
+        for shape, ts in order:                       # largest group first, each to the least-loaded stream
+            k = load.index(min(load))
+            load[k] += shape[0] * shape[1] * len(ts)
+            with torch.cuda.stream(streams[k]):
+                run_group(shape, ts, k)
+        for s in streams[1:]:
+            main.wait_stream(s)
+
     def tile_process(self):
         """Runs the network on overlapping tiles and pastes the un-padded centres (upstream
-        semantics, tile for tile).  Equal-shaped tiles are evaluated ``tile_batch`` at a time in one
-        forward call: batch elements are independent, so the values equal the serial loop's."""
+        semantics, tile for tile); see run_tiles for the batching / stream spreading."""
         batch, channel, height, width = self.img.shape
         s = self.scale
         self.output = self.img.new_zeros((batch, channel, height * s, width * s))
-        grid = self.tile_grid(height, width)
-        groups = {}
-        for t in grid:
-            (py0, py1, px0, px1) = t[0]
-            groups.setdefault((py1 - py0, px1 - px0), []).append(t)
-        for (th, tw), tiles in groups.items():
-            nb = self.batch_for(th, tw, len(tiles)) if batch == 1 else 1
-            for i in range(0, len(tiles), nb):
-                chunk = tiles[i:i + nb]
-                if len(chunk) == 1:
-                    (py0, py1, px0, px1) = chunk[0][0]
-                    inp = self.img[:, :, py0:py1, px0:px1]
-                else:
-                    inp = torch.cat([self.img[:, :, t[0][0]:t[0][1], t[0][2]:t[0][3]] for t in chunk], 0)
-                with torch.no_grad():
-                    out = self.model(inp)
-                for j, (_, (oy0, oy1, ox0, ox1), (cy0, cy1, cx0, cx1)) in enumerate(chunk):
-                    o = out[j:j + 1] if len(chunk) > 1 else out
-                    self.output[:, :, oy0:oy1, ox0:ox1] = o[:, :, cy0:cy1, cx0:cx1]
+        tiles = [(py0, py1, px0, px1, (o, c)) for ((py0, py1, px0, px1), o, c) in self.tile_grid(height, width)]
+
+        def paste(payload, out):
+            (oy0, oy1, ox0, ox1), (cy0, cy1, cx0, cx1) = payload
+            self.output[:, :, oy0:oy1, ox0:ox1] = out[:, :, cy0:cy1, cx0:cx1]
+
+        self.run_tiles(self.img, tiles, paste)
 
     def post_process(self):
         if self.mod_scale is not None:

@@ -93,8 +93,9 @@ class RRDBNet(nn.Module):
         self.num_grow_ch = num_grow_ch
         self.compute_dtype = compute_dtype
         self._build_params()
-        self._ctx = None          # (ctypes handle, device index, dtype code)
+        self._ctx = None          # (ctypes handle, device index, dtype code): slot 0
         self._dirty = True        # parameters changed since the last upload
+        self._extra = {}          # slot -> (handle, device index, dtype code): replicas for concurrent streams
 
     # ------------------------------------------------------------------ parameters
     def _build_params(self):
@@ -136,6 +137,9 @@ class RRDBNet(nn.Module):
         if self._ctx is not None:
             _lib.load().nesr_destroy(self._ctx[0])
             self._ctx = None
+        for h in getattr(self, "_extra", {}).values():
+            _lib.load().nesr_destroy(h[0])
+        self._extra = {}
         self._dirty = True
 
     def __del__(self):
@@ -153,12 +157,42 @@ class RRDBNet(nn.Module):
             return _lib.DTYPE_BF16
         raise ValueError(f"compute_dtype {self.compute_dtype!r}: expected 'f32' or 'bf16'")
 
-    def _context(self, device: torch.device):
+    def _upload(self, handle):
+        lib = _lib.load()
+        for key, t in self.state_dict().items():
+            arr = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+            shape = (ctypes.c_int64 * arr.dim())(*arr.shape)
+            _lib.check(lib.nesr_load_weight(handle, key.encode(), ctypes.c_void_p(arr.data_ptr()), shape, arr.dim()),
+                       f"nesr_load_weight({key})")
+        _lib.check(lib.nesr_finalize_weights(handle), "nesr_finalize_weights")
+
+    def _create(self, index, code):
+        handle = ctypes.c_void_p()
+        unshuffle = {2: 2, 1: 4}.get(self.scale, 0)
+        _lib.check(_lib.load().nesr_create(ctypes.byref(handle), index, conv_first_in_ch(self.num_in_ch, self.scale),
+                                           unshuffle, self.num_feat, self.num_block, self.num_grow_ch, self.num_out_ch, code),
+                   "nesr_create")
+        return handle
+
+    def _context(self, device: torch.device, slot: int = 0):
+        """HIP context of `slot`.  Slot 0 is the model's own; further slots are replicas (own packed
+        weights and workspace) so independent forward calls can run concurrently on different streams."""
         lib = _lib.load()
         index = device.index if device.index is not None else torch.cuda.current_device()
         code = self._dtype_code()
         if self._ctx is not None and (self._ctx[1] != index or self._ctx[2] != code):
             self._release()
+        if self._dirty and self._extra:
+            for h in self._extra.values():
+                lib.nesr_destroy(h[0])
+            self._extra = {}
+        if slot != 0:
+            self._context(device, 0)   # slot 0 first: settles device / dtype / dirty state
+            if slot not in self._extra:
+                handle = self._create(index, code)
+                self._upload(handle)
+                self._extra[slot] = (handle, index, code)
+            return self._extra[slot][0]
         if self._ctx is None:
             handle = ctypes.c_void_p()
             unshuffle = {2: 2, 1: 4}.get(self.scale, 0)
@@ -190,8 +224,9 @@ class RRDBNet(nn.Module):
                 f"{x.device}. There is no CPU/PyTorch fallback for this path.")
 
     @torch.no_grad()
-    def forward(self, x):
-        """x: [N, num_in_ch, H, W] float on a ROCm device -> [N, num_out_ch, H*s, W*s]."""
+    def forward(self, x, slot: int = 0):
+        """x: [N, num_in_ch, H, W] float on a ROCm device -> [N, num_out_ch, H*s, W*s].
+        `slot` selects a context replica (see _context); work is enqueued on torch's current stream."""
         self._require_cuda(x)
         if x.dim() != 4:
             raise ValueError(f"expected NCHW input, got shape {tuple(x.shape)}")
@@ -203,7 +238,7 @@ class RRDBNet(nn.Module):
             raise AssertionError(f"hh({h}) and hw({w}) must be divisible by {u}")  # upstream pixel_unshuffle asserts
         s = self.out_scale()
         with torch.cuda.device(xf.device):
-            ctx = self._context(xf.device)
+            ctx = self._context(xf.device, slot)
             y = torch.empty((n, self.num_out_ch, h * s, w * s), dtype=torch.float32, device=xf.device)
             stream = torch.cuda.current_stream(xf.device).cuda_stream
             _lib.check(_lib.load().nesr_forward(ctx, ctypes.c_void_p(xf.data_ptr()), n, c, h, w,
@@ -245,8 +280,9 @@ class RRDBNet(nn.Module):
         return 2.0 * macs * px
 
     def set_kernel_timing(self, device, enable=True):
-        ctx = self._context(torch.device(device))
-        _lib.check(_lib.load().nesr_set_kernel_timing(ctx, 1 if enable else 0), "nesr_set_kernel_timing")
+        handles = [self._context(torch.device(device))] + [h[0] for h in self._extra.values()]
+        for ctx in handles:
+            _lib.check(_lib.load().nesr_set_kernel_timing(ctx, 1 if enable else 0), "nesr_set_kernel_timing")
 
     def preferred_batch(self, device, h, w, max_batch):
         """Tiles of h x w input per forward call that fill the GPU's CUs most evenly (<= max_batch)."""
@@ -262,10 +298,15 @@ class RRDBNet(nn.Module):
         """(total ms, launches, algorithmic flops) of the dense-block convs since the last call."""
         if self._ctx is None:
             return 0.0, 0, 0.0
-        ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-        _lib.check(_lib.load().nesr_kernel_time_ms(self._ctx[0], ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)),
-                   "nesr_kernel_time_ms")
-        return ms.value, n.value, fl.value
+        tot_ms, tot_n, tot_fl = 0.0, 0, 0.0
+        # replicas run on concurrent streams: their brackets overlap in wall time, so the sum of the
+        # bracketed times is an upper bound of the busy time (the derived TFLOP/s a lower bound)
+        for h in [self._ctx] + list(self._extra.values()):
+            ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+            _lib.check(_lib.load().nesr_kernel_time_ms(h[0], ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)),
+                       "nesr_kernel_time_ms")
+            tot_ms, tot_n, tot_fl = tot_ms + ms.value, tot_n + n.value, tot_fl + fl.value
+        return tot_ms, tot_n, tot_fl
 
 
 def conv3x3(x, weight, bias, lrelu=False, upsample=False, dtype="f32"):

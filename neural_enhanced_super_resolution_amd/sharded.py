@@ -139,19 +139,12 @@ def enhance_sharded(up, band, frame_hw, group=None, gather=True):
         x = normalize_u8_on_device(local.permute(2, 0, 1).flip(0)).unsqueeze(0)   # BGR->RGB, /255, HWC->NCHW
         if up.half:
             x = x.half()
-        groups = {}
-        for t in mine:
-            groups.setdefault((t.inp[1] - t.inp[0], t.inp[3] - t.inp[2]), []).append(t)
-        for (th, tw), ts in groups.items():
-            nb = up.batch_for(th, tw, len(ts))
-            for i in range(0, len(ts), nb):
-                chunk = ts[i:i + nb]
-                inp = torch.cat([x[:, :, t.inp[0] - n0:t.inp[1] - n0, t.inp[2]:t.inp[3]] for t in chunk], 0)
-                out = up.model(inp)
-                for j, t in enumerate(chunk):
-                    o = out[j, :, t.crop[0]:t.crop[1], t.crop[2]:t.crop[3]].float().clamp_(0, 1)
-                    q = (o.flip(0).permute(1, 2, 0) * 255.0).round().to(torch.uint8).contiguous()   # RGB->BGR, CHW->HWC
-                    results.append((t, q))
+        def quantise(t, out):
+            o = out[0, :, t.crop[0]:t.crop[1], t.crop[2]:t.crop[3]].float().clamp_(0, 1)
+            q = (o.flip(0).permute(1, 2, 0) * 255.0).round().to(torch.uint8).contiguous()   # RGB->BGR, CHW->HWC
+            results.append((t, q))
+
+        up.run_tiles(x, [(t.inp[0] - n0, t.inp[1] - n0, t.inp[2], t.inp[3], t) for t in mine], quantise)
     if not gather:
         return [(t.out, q) for t, q in results]
 

@@ -121,7 +121,7 @@ WINO_TOL = 2e-5   # relative to max|ref|: Winograd's transforms add a few ulps t
 
 
 @pytest.mark.parametrize("cin,cout", [(16, 64), (64, 32), (96, 32), (128, 32), (160, 32), (192, 64), (64, 64)])
-@pytest.mark.parametrize("hw", [(24, 40), (9, 17), (33, 47)])
+@pytest.mark.parametrize("hw", [(24, 40), (9, 17), (33, 47), (1, 1), (2, 3), (7, 5)])
 def test_conv3x3_f32_winograd_matches_torch(cuda_device, cin, cout, hw):
     from neural_enhanced_super_resolution_amd import conv3x3
     x, w, b = _case(cin, cout, hw[0], hw[1], seed=cin * 7 + cout + hw[0], n=2)
