@@ -28,6 +28,8 @@
 //   epilogue  : the 16 M_p of a (tile, 4 couts) live in one lane -> output transform in registers,
 //               then bias / LeakyReLU / residuals and 16-byte stores of 4 consecutive channels for
 //               each of the tile's 2x2 pixels (same fused epilogue semantics as the direct kernel).
+#include <cstdlib>
+
 #include "nesr_kernels.h"
 
 namespace nesr {
@@ -57,9 +59,12 @@ constexpr int TH = 8, TW = 16, PH = TH + 2, PW = TW + 2, NPIX = PH * PW;   // 18
 constexpr int IN_ITEMS = 2 * NPIX;                                          // 16-byte staging items (4 channels each)
 constexpr int IN_BYTES = 4 * NPIX * 8;                                      // 4 kq planes x pixel x 8 B = 5760
 
-template <int NT, int STAGES>
-__global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
-    constexpr int COUT = 32 * NT;
+// NT = 16-channel groups per wave, CW = waves across the output channels (Cout = 16 * NT * CW); the
+// workgroup has 2 * CW waves (two tile-halves).
+template <int NT, int STAGES, int CW>
+__global__ __launch_bounds__(128 * CW, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
+    constexpr int THREADS = 128 * CW;
+    constexpr int COUT = 16 * NT * CW;
     constexpr int W_BYTES = 16 * COUT * 32;          // per chunk: 16 positions x COUT x 8 ch x 4 B
     constexpr int W_ITEMS = W_BYTES / 16;            // 512 * NT * 2
     constexpr int STAGE_BYTES = IN_BYTES + W_BYTES;
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
     // ---- staging.  Input halo tile: global -> registers -> LDS (the 16-byte items are split into the
     // two 8-byte kq planes; branch-free, zero padding by select).  Weight slab: a linear copy of
     // W_BYTES, done by LDS-DMA from inline asm (no staging registers, no ds_write issue slots).
-    constexpr int RI = (IN_ITEMS + 255) / 256;   // 2
+    constexpr int RI = (IN_ITEMS + THREADS - 1) / THREADS;
     const char* src[RI];
     int dst[RI];
     bool zero[RI], has[RI];
@@ -87,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
         const char* in = static_cast<const char*>(a.in);
 #pragma unroll
         for (int i = 0; i < RI; ++i) {
-            const int k0 = tid + 256 * i;
+            const int k0 = tid + THREADS * i;
             has[i] = k0 < IN_ITEMS;
             const int k = has[i] ? k0 : IN_ITEMS - 1;
             const int half = k >= NPIX ? 1 : 0;       // channels 4*half .. 4*half+3 -> planes 2*half, 2*half+1
@@ -123,20 +128,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
     const unsigned lds_base = (unsigned)(size_t)(lds_char*)(smem);
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const char* wsrc = static_cast<const char*>(a.w) + tid * 16;
-    constexpr int WR = W_ITEMS / 256;   // whole rounds: W_ITEMS = 1024 * NT
+    constexpr int WR = W_ITEMS / THREADS;   // whole rounds: W_ITEMS = 512 * NT * CW
     auto dma_weights = [&](int c, int stage) {
         const unsigned d0 = lds_base + stage * STAGE_BYTES + IN_BYTES + wave_u * 1024;
         const char* s0 = wsrc + (size_t)c * W_BYTES;
 #pragma unroll
-        for (int i = 0; i < WR; ++i) glds16_asm(s0 + i * 4096, __builtin_amdgcn_readfirstlane(d0 + i * 4096));
+        for (int i = 0; i < WR; ++i) glds16_asm(s0 + i * (THREADS * 16), __builtin_amdgcn_readfirstlane(d0 + i * (THREADS * 16)));
     };
 
     // ---- per-lane coordinates
     const int j = lane & 15, kq = lane >> 4;
-    const int half = wave >> 1, cgw = wave & 1;
+    const int half = wave / CW, cgw = wave % CW;
     const int tr = 2 * half + (j >> 3), tc = j & 7;                      // Winograd tile inside the workgroup tile
     const int patch0 = kq * (NPIX * 8) + ((2 * tr) * PW + 2 * tc) * 8;    // byte offset of patch pixel (0,0), plane kq
-    // weights: [p][cout group g = NT*cgw + t][kq][16][2 ch]: lane reads 8 B at ((p*2NT + g)*4 + kq)*128 + j*8
+    // weights: [p][cout group g = NT*cgw + t][kq][16][2 ch]: lane reads 8 B at ((p*NT*CW + g)*4 + kq)*128 + j*8
     const int w0 = IN_BYTES + ((NT * cgw) * 4 + kq) * 128 + j * 8;
 
     f32x4 acc[NT][16];
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
     constexpr bool PIPE = STAGES == 3;
     // conv_last (cout_real <= 16 real channels, planar / u8 output): the waves of the second
     // 16-channel group have nothing to compute -- they only help staging and keep the barriers
-    const bool idle = NT == 1 && a.cout_real > 0 && cgw == 1;
+    const bool idle = NT == 1 && CW == 2 && a.cout_real > 0 && cgw == 1;
 
     int s_cur = 0, s_nxt = 1 % STAGES, s_fill = STAGES - 1;
     f32x2 V[16];
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) b_row(tn, V, r);
         }
-        auto U = [&](int p, int t) -> f32x2 { return *reinterpret_cast<const f32x2*>(st + w0 + (p * 2 * NT + t) * 512); };
+        auto U = [&](int p, int t) -> f32x2 { return *reinterpret_cast<const f32x2*>(st + w0 + (p * NT * CW + t) * 512); };
         f32x2 ua[2], ub[2];
         if constexpr (NT == 2) { ua[0] = U(0, 0); ub[0] = U(0, 1); } else { ua[0] = U(0, 0); ub[0] = U(1, 0); }
         __builtin_amdgcn_sched_barrier(0);
@@ -346,19 +351,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
     }
 }
 
-template <int NT, int STAGES>
+template <int NT, int STAGES, int CW>
 hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
-    constexpr size_t shm = STAGES * (size_t)(IN_BYTES + 16 * 32 * NT * 32);
+    constexpr size_t shm = STAGES * (size_t)(IN_BYTES + 16 * (16 * NT * CW) * 32);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32_kernel<NT, STAGES>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32_kernel<NT, STAGES, CW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int tiles = ((a.w_ + TW - 1) / TW) * ((a.h + TH - 1) / TH) * a.n;
     if (tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL((conv3x3_wino_f32_kernel<NT, STAGES>), dim3(tiles), dim3(256), shm, s, a);
+    hipLaunchKernelGGL((conv3x3_wino_f32_kernel<NT, STAGES, CW>), dim3(tiles), dim3(128 * CW), shm, s, a);
     return hipGetLastError();
 }
 
@@ -391,8 +396,15 @@ void pack_weights_wino_f32(const float* oihw, int cout, int cin, int cin_p, int 
 hipError_t launch_conv3x3_wino_f32(const ConvArgs& a, hipStream_t s) {
     if (a.cin % 8) return hipErrorInvalidValue;
     if ((a.out_nchw || a.out_u8) && (a.coutp != 32 || a.cout_real < 1 || a.cout_real > 4)) return hipErrorInvalidValue;
-    if (a.coutp == 64) return launch_wino<2, 2>(a, s);   // 2 x 38.5 KB -> two workgroups per CU
-    if (a.coutp == 32) return launch_wino<1, 3>(a, s);   // 3 x 22.1 KB -> two workgroups per CU
+    // NESR_WINO_NT1=wide: Cout=32 layers as 2-wave workgroups, each wave owning both 16-channel groups
+    // (no redundant input transform between cout-group waves, but one wave per SIMD on a 256x256 frame):
+    // measured 29 % slower in-process, kept for A/B
+    static const bool wide = [] { const char* e = getenv("NESR_WINO_NT1"); return e && e[0] == 'w'; }();
+    if (a.coutp == 64) return launch_wino<2, 2, 2>(a, s);   // 2 x 38.5 KB -> two workgroups per CU
+    if (a.coutp == 32) {
+        if (wide && !(a.out_nchw || a.out_u8)) return launch_wino<2, 3, 1>(a, s);
+        return launch_wino<1, 3, 2>(a, s);                   // 3 x 22.1 KB -> two workgroups per CU
+    }
     return hipErrorInvalidValue;
 }
 
