@@ -1,4 +1,7 @@
-// 3x3 convolution as im2col-free implicit GEMM on the gfx950 matrix cores.
+// 3x3 convolution as im2col-free implicit GEMM on the gfx950 matrix cores -- the DIRECT form.
+// (The default f32 path is the Winograd kernel, conv3x3_wino_f32.hip; this kernel is the exact
+// reference point `f32-direct`, the bf16 path for small frames, and the body of the opt-in
+// persistent trunk kernel at the end of this file.)
 //
 //   f32  : v_mfma_f32_32x32x2_f32   (exact f32, bitwise a k-ordered fmaf chain; 157 TFLOP/s peak)
 //   bf16 : v_mfma_f32_32x32x16_bf16 (bf16 operands, f32 accumulate; ~2.5 PFLOP/s dense peak)
@@ -21,9 +24,11 @@
 //               matching ds_read_b128 is lane-contiguous (conflict-free).
 //   LDS image : activations [h][pixel][16 B] (two planes), so 16 consecutive pixels are 256
 //               contiguous bytes.
-//   epilogue  : bias, LeakyReLU(0.2), up to two scaled residuals (RDB: x5*0.2+x; RRDB: out*0.2+x),
-//               NHWC channel-slice store (the concat-free dense block), optional planar NCHW or
-//               clamped/quantised u8 HWC store for conv_last.
+//   epilogue  : weights are the MFMA A operand and pixels the B operand, so a lane owns runs of 4
+//               consecutive channels of one pixel: bias, LeakyReLU(0.2), up to two scaled residuals
+//               (RDB: x5*0.2+x; RRDB: out*0.2+x), 16-byte channel-slice stores through the Map
+//               addressing (the concat-free dense block), optional planar NCHW or clamped/quantised
+//               u8 HWC store for conv_last.
 #include <hip/hip_bf16.h>
 
 #include <cstdlib>
