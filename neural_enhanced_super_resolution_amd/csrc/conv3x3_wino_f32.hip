@@ -61,6 +61,19 @@ constexpr int IN_BYTES = 4 * NPIX * 8;                                      // 4
 
 // NT = 16-channel groups per wave, CW = waves across the output channels (Cout = 16 * NT * CW); the
 // workgroup has 2 * CW waves (two tile-halves).
+// 16-byte feature-map store, write-through (sc1): the lines leave L2 while the kernel runs instead of
+// as a dirty write-back at the kernel boundary (MI355X_MICROARCH.md, price list row "boundary":
+// + B / 6 TB/s for B dirty bytes; 8-17 MB per launch here).  In-process A/B: -1.9 % frame time.
+// Inline asm because no builtin carries the sc1 bit on a flat global store; the trailing s_nop keeps
+// hipcc from reusing the data registers before the store has read them (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void store_fm(float* p, f32x4 v) {
+#ifdef NESR_PLAIN_STORES
+    *reinterpret_cast<f32x4*>(p) = v;
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#endif
+}
+
 template <int NT, int STAGES, int CW>
 __global__ __launch_bounds__(128 * CW, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
     constexpr int THREADS = 128 * CW;
@@ -330,8 +343,8 @@ __global__ __launch_bounds__(128 * CW, 2) void conv3x3_wino_f32_kernel(ConvArgs 
                     for (int q = 0; q < 4; ++q) v[q] = __fadd_rn(__fmul_rn(v[q], a.s2), r[q]);
                 }
                 if (valid) {
-                    if (out) *reinterpret_cast<f32x4*>(out + at(a.out_map, a.out_coff + co)) = v;
-                    if (out2) *reinterpret_cast<f32x4*>(out2 + at(a.out2_map, co)) = v;
+                    if (out) store_fm(out + at(a.out_map, a.out_coff + co), v);
+                    if (out2) store_fm(out2 + at(a.out2_map, co), v);
                     if (a.cout_real > 0 && co == 0) {
                         // conv_last: channels 0..cout_real-1 (<= 4) are this lane's run (cgw = 0, kq = 0)
 #pragma unroll
