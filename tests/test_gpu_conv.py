@@ -147,3 +147,25 @@ def test_conv3x3_f32_winograd_one_hot_taps_and_upsample(cuda_device):
     ref = F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), ws, bs, padding=1)
     got = conv3x3(xs.to(cuda_device), ws, bs, upsample=True, dtype="f32-winograd").cpu()
     assert (got - ref).abs().max().item() < WINO_TOL * max(1.0, ref.abs().max().item())
+
+
+def test_winograd_vs_direct_random_shapes(cuda_device):
+    """Seeded sweep over ragged shapes / batches / channel counts: the Winograd and the direct kernels
+    implement the same convolution, so they must agree to a few ulps of the accumulation everywhere
+    (catches tile-edge, odd-size and batch indexing slips that fixed shapes can miss)."""
+    from neural_enhanced_super_resolution_amd import conv3x3
+    rng = np.random.default_rng(123)
+    for _ in range(24):
+        n = int(rng.integers(1, 4))
+        h, w = int(rng.integers(1, 41)), int(rng.integers(1, 41))
+        cin = int(rng.choice([3, 8, 12, 16, 64, 96, 192]))
+        cout = int(rng.choice([3, 32, 64]))
+        up = bool(rng.integers(0, 2)) and h * w < 400
+        lrelu = bool(rng.integers(0, 2))
+        x, wt, b = _case(cin, cout, h, w, seed=int(rng.integers(1 << 30)), n=n)
+        xd = x.to(cuda_device)
+        a = conv3x3(xd, wt, b, lrelu=lrelu, upsample=up, dtype="f32-direct").cpu()
+        c = conv3x3(xd, wt, b, lrelu=lrelu, upsample=up, dtype="f32-winograd").cpu()
+        assert a.shape == c.shape
+        tol = WINO_TOL * max(1.0, a.abs().max().item())
+        assert (a - c).abs().max().item() < tol, (n, cin, cout, h, w, up, lrelu)
