@@ -32,7 +32,10 @@ typedef struct nesr_ctx nesr_ctx;
 /* NESR_DTYPE_F32_WINOGRAD: f32 storage and f32 matrix-core arithmetic, the feature-map 3x3 convs
  * evaluated by Winograd F(2x2,3x3) (2.25x less matrix work; a few ulps per layer away from the
  * direct form, far inside the 1e-3 output tolerance). */
-enum { NESR_DTYPE_F32 = 0, NESR_DTYPE_BF16 = 1, NESR_DTYPE_F32_WINOGRAD = 2 };
+/* NESR_DTYPE_F32_SPLIT: f32 in, f32 out, f32 accumulation; every conv operand is carried as an exact-sum
+ * pair of halves (x = hi + lo) and each product is three f16 MFMAs (hi*hi + hi*lo + lo*hi), see
+ * conv3x3_f16x2.hip.  Whole-network max abs error vs an f64 evaluation 3e-6 (plain f32: 1e-6). */
+enum { NESR_DTYPE_F32 = 0, NESR_DTYPE_BF16 = 1, NESR_DTYPE_F32_WINOGRAD = 2, NESR_DTYPE_F32_SPLIT = 3 };
 enum { NESR_ROUND_TRUNC = 0, NESR_ROUND_NEAREST = 1 };
 
 enum {

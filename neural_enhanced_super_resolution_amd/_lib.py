@@ -13,7 +13,7 @@ import threading
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libnesr_hip.so")
 
-DTYPE_F32, DTYPE_BF16, DTYPE_F32_WINOGRAD = 0, 1, 2
+DTYPE_F32, DTYPE_BF16, DTYPE_F32_WINOGRAD, DTYPE_F32_SPLIT = 0, 1, 2, 3
 ROUND_TRUNC, ROUND_NEAREST = 0, 1
 
 # name -> (restype, argtypes); must list every symbol include/nesr_hip.h declares

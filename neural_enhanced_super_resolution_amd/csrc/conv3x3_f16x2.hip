@@ -1,0 +1,487 @@
+// f32 3x3 convolution on the f16 matrix cores: every f32 operand travels as an exact-sum pair of
+// halves (x = hi + lo, hi = f16(x), lo = f16(x - hi): 22-23 significant bits, f16 subnormals
+// included) and the product is accumulated in f32 from three MFMAs
+//
+//     w*x  ~=  w_hi*x_hi + w_hi*x_lo + w_lo*x_hi                (dropped: w_lo*x_lo ~ 2^-22 |w x|)
+//
+// v_mfma_f32_32x32x16_f16 runs at 16x the rate of the f32 MFMA, so three of them cost 3/16 of the
+// direct f32 kernel's matrix time and 27/64 of the Winograd kernel's.  Measured on the 23-block
+// network against an f64 evaluation of the same weights (tools/probes/split_accuracy.py): max abs
+// error 3.1e-6 for this scheme, 1.2e-6 for plain f32 (torch CPU), i.e. the same class of error
+// as the Winograd kernel -- 300x inside the 1e-3 tolerance.  The MFMA honours f16 subnormal inputs
+// on gfx950 (tools/probes/mfma_f16_denorm.hip), so lo needs no scaling; |x| is clamped to 65504.
+//
+// Activations live pre-split in HBM, channel-blocked like the bf16 path: per 16-channel K-chunk a
+// pixel owns 64 bytes = [16 hi halves | 16 lo halves] (Map: pix = 32, chunk = pixels * 32, in
+// 2-byte units); the producing kernel's epilogue splits once, the consumers feed LDS by LDS-DMA
+// without touching a VGPR.  Same 4 bytes per value as f32 storage.
+//
+//   workgroup : 4 waves, output tile 8 or 16 rows x 32 cols x 32 output channels; wave w owns rows
+//               RW w .. RW w + RW - 1 (the MFMA's 32 columns = 32 pixels of a row).  Layers with 64
+//               output channels run two workgroups per tile (adjacent in the launch order).
+//               (-DNESR_SPLIT_WAVES=8 builds the 8-wave form of the same tiles: measured 3-5 % slower.)
+//   K loop    : 16-channel chunks; input halo tile [(rows+2) x 34 pixels][64 B] and weight slab
+//               [9 taps][hi|lo][k half][32 couts][16 B] by LDS-DMA into 2-slot rings, counted
+//               vmcnt waits + one barrier per chunk (as conv3x3_bf16.hip).
+//   LDS image : pixel p's 16-byte slot s = 2*plane + k-half sits at p*64 + (s ^ ((col>>2)&3))*16:
+//               the 16-lane groups of ds_read_b128 (MI355X_MICROARCH.md, LDS) then cover all 16
+//               slots of a 256-byte bank row for every horizontal tap.
+//   epilogue  : bias / LeakyReLU / residuals in f32 (residuals re-joined hi + lo), split, 16-byte
+//               write-through stores of 8 channels per plane; conv_last writes planar f32 / u8.
+#include <cstdlib>
+
+#include "nesr_kernels.h"
+
+namespace nesr {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char lds_char;
+
+namespace {
+
+constexpr int TW = 32, PW = TW + 2;
+#ifndef NESR_SPLIT_WAVES
+#define NESR_SPLIT_WAVES 4
+#endif
+constexpr int WAVES = NESR_SPLIT_WAVES;          // waves per workgroup
+constexpr int RW_S = 8 / WAVES, RW_L = 16 / WAVES;   // rows per wave of the 8x32 and the 16x32 tile
+
+template <int RW>
+struct Geo {
+    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int TH = WAVES * RW;
+    static constexpr int PH = TH + 2;
+    static constexpr int NPIX = PH * PW;
+    static constexpr int IN_ITEMS = 4 * NPIX;   // 16-byte items per input slot
+    static constexpr int IN_ROUNDS = (IN_ITEMS + THREADS - 1) / THREADS;
+    static constexpr int IN_BYTES = IN_ITEMS * 16;
+};
+constexpr int W_ITEMS1 = 9 * 2 * 2 * 32;   // 16-byte items of one 32-cout weight slab (per K-chunk)
+
+// LDS-DMA from inline asm (see conv3x3_bf16.hip): not counted by hipcc, waited for by hand.
+__device__ __forceinline__ void glds16_asm(const char* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+// the same with a scalar 64-bit base and an unsigned 32-bit per-lane byte offset
+__device__ __forceinline__ void glds16_s(const char* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+// Plain (write-back) stores: every workgroup of a layer reaches its epilogue at about the same time, and
+// the write-through form (sc1) that helps the Winograd kernel made this burst 3x longer here
+// (in-kernel stamps: 12.4k -> 3.7k cycles per epilogue; -4 % / -6 % forward time on 1 / 6 tiles).
+__device__ __forceinline__ void store16(uint16_t* p, uint4 v) {
+#ifdef NESR_SC1_STORES
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(f32x4, v)) : "memory");
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+
+// x -> (hi, lo) halves of 4 values
+__device__ __forceinline__ void split4(f32x4 v, uint2& hi, uint2& lo) {
+    f16x4 h, l;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x = fminf(fmaxf(v[q], -65504.f), 65504.f);
+        const _Float16 hq = (_Float16)x;
+        h[q] = hq;
+        l[q] = (_Float16)(x - (float)hq);
+    }
+    hi = __builtin_bit_cast(uint2, h);
+    lo = __builtin_bit_cast(uint2, l);
+}
+// 4 consecutive channels of a split feature map: p -> hi halves, lo halves 16 elements on
+__device__ __forceinline__ f32x4 ld4_split(const uint16_t* p) {
+    const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+    const f16x4 l = *reinterpret_cast<const f16x4*>(p + 16);
+    return f32x4{(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
+}
+
+#ifndef NESR_ABL
+#define NESR_ABL 0   // timing ablations: 1 empty kernel, 2 stop after the prologue, 4 no epilogue, 8 no MFMA, 16 no K-loop DMA, 64 cycle stamps
+#endif
+#if NESR_ABL & 64
+__device__ unsigned long long g_stamps[256];
+#define STAMP(i) do { if (stamping) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0 && (i) < 256) g_stamps[(i)] = t_; } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+template <int RW, int ISLOTS>
+__global__ __launch_bounds__(64 * WAVES, (WAVES / 4) * (RW == RW_S ? 2 : 1)) void conv3x3_f16x2_kernel(ConvArgs a) {
+    if (NESR_ABL & 1) return;
+    typedef Geo<RW> G;
+    constexpr int THREADS = G::THREADS, TH = G::TH;
+    constexpr int IN_ITEMS = G::IN_ITEMS, IN_ROUNDS = G::IN_ROUNDS, IN_BYTES = G::IN_BYTES;
+    constexpr int W_ITEMS = W_ITEMS1;
+    constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
+    constexpr int W_BYTES = W_ITEMS * 16;
+    constexpr int WRING = ISLOTS * IN_BYTES;   // LDS: [input ring][weight ring: 2 x W_BYTES]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if NESR_ABL & 64
+    const bool stamping = blockIdx.x == 77 && wave == 1;
+#endif
+    STAMP(0);
+
+    static_assert(ISLOTS == 2, "two-slot rings: every wait is vmcnt(0)");
+    // ---- XCD-aware work index (bijective for any count); the cout groups of one tile are neighbours
+    const int CG = a.coutp >> 5;
+    const int tiles_x = (a.w_ + TW - 1) / TW;
+    const int tiles_y = (a.h + TH - 1) / TH;
+    const int total = tiles_x * tiles_y * a.n * CG;
+    int idx;
+    {
+        const int bid = blockIdx.x, q = total >> 3, r = total & 7, xcd = bid & 7;
+        idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    STAMP(5);
+    const int cg = idx % CG;
+    int tile = idx / CG;
+    const int n = tile / (tiles_x * tiles_y);
+    tile -= n * tiles_x * tiles_y;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    // ---- LDS-DMA plan.  LDS item k of an input slot = padded pixel k>>2, physical slot k&3; it holds
+    // logical slot (k&3) ^ ((padded column >> 2) & 3) of that pixel's 64 bytes.  Item k = tid + THREADS*i
+    // belongs to this lane in round i; its source is (scalar base of image n and chunk c) + voff[i].
+    // Out-of-image items (the conv's zero padding) are the same for every chunk: they are zeroed once in
+    // every ring slot and left out of the DMAs (EXEC-masked lanes do not write).
+    const unsigned lds_base = (unsigned)(size_t)(lds_char*)(smem);
+    unsigned voff[IN_ROUNDS];
+    unsigned okmask = 0;
+    {
+        int p = tid >> 2;
+        int py = p / PW, px = p - py * PW;
+        const int sl = tid & 3;
+#pragma unroll
+        for (int i = 0; i < IN_ROUNDS; ++i) {
+            const int k = tid + THREADS * i;
+            const int sg = sl ^ ((px >> 2) & 3);
+            const int Y = y0 - 1 + py, X = x0 - 1 + px;
+            const bool has = k < IN_ITEMS;
+            const bool ok = has && Y >= 0 && Y < a.h && X >= 0 && X < a.w_;
+            voff[i] = ((unsigned)(Y >> a.up) * (unsigned)a.in_w + (unsigned)(X >> a.up)) * 64u + sg * 16;
+            okmask |= ok ? (1u << i) : 0u;
+            if (has && !ok) {
+#pragma unroll
+                for (int sl2 = 0; sl2 < ISLOTS; ++sl2) *reinterpret_cast<f32x4*>(smem + sl2 * IN_BYTES + k * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            px += (THREADS / 4) % PW;
+            py += (THREADS / 4) / PW;
+            if (px >= PW) { px -= PW; py += 1; }
+        }
+    }
+    STAMP(6);
+    const char* in_img = static_cast<const char*>(a.in) + (size_t)n * a.in_h * a.in_w * 64;
+    const long long in_cstride = a.in_map.chunk * 2;   // bytes between K-chunks
+    const char* wbase = static_cast<const char*>(a.w) + (size_t)cg * W_BYTES;
+    const long long w_cstride = (long long)CG * W_BYTES;
+    // DMA round j of chunk c: rounds [0, W_ROUNDS) move the weight slab, the rest the input tile
+    constexpr int NDMA = W_ROUNDS + IN_ROUNDS;
+    auto dma_round = [&](int c, int wslot, int islot_, int j) {   // j is a compile-time constant at every call site
+        if (j < W_ROUNDS) {
+            const int k = tid + THREADS * j;
+            const unsigned dst = lds_base + WRING + wslot * W_BYTES + j * (THREADS * 16) + wave * 1024;
+            if (k < W_ITEMS) glds16_s(wbase + (long long)c * w_cstride, (unsigned)k * 16u, __builtin_amdgcn_readfirstlane(dst));
+        } else if (j < NDMA) {
+            const int i = j - W_ROUNDS;
+            const unsigned dst = lds_base + islot_ * IN_BYTES + i * (THREADS * 16) + wave * 1024;
+            if ((okmask >> i) & 1u) glds16_s(in_img + (long long)c * in_cstride, voff[i], __builtin_amdgcn_readfirstlane(dst));
+        }
+    };
+
+    // ---- per-lane operand coordinates
+    const int m = lane & 31, hh = lane >> 5;
+    // byte offset inside an input slot of this lane's hi fragment for horizontal tap dx, row 0 of the
+    // wave's RW + 2; the lo fragment is the same offset ^ 32
+    int p_off[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) p_off[dx] = ((RW * wave) * PW + m + dx) * 64 + ((hh ^ (((m + dx) >> 2) & 3)) << 4);
+    const int w_off = hh * 32 + m;   // item index inside a weight slab: ((tap*2 + plane)*2 + hh)*32 + cout
+    const bool active = (y0 + RW * wave) < a.h;
+
+    // accumulators: [row][0] takes w_hi*x_hi, [row][1] the two cross terms (summed in the epilogue):
+    // consecutive MFMAs never wait on each other's result, and the small terms add up among themselves
+    f32x16 acc[RW][2];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[r][0][e] = acc[r][1][e] = 0.f;
+    // bias now, so that its latency hides under the K loop
+    f32x4 bs[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bs[g] = *reinterpret_cast<const f32x4*>(a.bias + 32 * cg + 8 * g + 4 * hh);
+
+    const int nchunks = a.cin / 16;
+    STAMP(7);
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) dma_round(0, 0, 0, j);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero padding is in LDS before the first barrier
+    STAMP(1);
+    if (NESR_ABL & 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+    for (int c = 0; c < nchunks; ++c) {
+        // this wave's DMAs of chunk c (issued during chunk c-1) have landed; after the barrier, everybody's
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(8 + 4 * c);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        STAMP(9 + 4 * c);
+        // the next chunk's DMAs go out first (beside the MFMAs each costs 150+ cycles of issue instead of ~85:
+        // measured, in-kernel stamps)
+        if (c + 1 < nchunks && !(NESR_ABL & 16)) {
+#pragma unroll
+            for (int j = 0; j < NDMA; ++j) dma_round(c + 1, (c + 1) & 1, (c + 1) & 1, j);
+        }
+        STAMP(10 + 4 * c);
+        if (active) {
+            const char* st = smem + (c & 1) * IN_BYTES;
+            const f32x4* sw = reinterpret_cast<const f32x4*>(smem + WRING + (c & 1) * W_BYTES);
+            auto pix_frag = [&](int r, int dx, int plane) -> f32x4 {
+                return *reinterpret_cast<const f32x4*>(st + (p_off[dx] ^ (plane << 5)) + r * (PW * 64));
+            };
+            f32x4 P[2][RW + 2][2];
+            f32x4 Wf[2][2];
+#pragma unroll
+            for (int r = 0; r < RW + 2; ++r) { P[0][r][0] = pix_frag(r, 0, 0); P[0][r][1] = pix_frag(r, 0, 1); }
+            Wf[0][0] = sw[w_off];
+            Wf[0][1] = sw[w_off + 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 9; ++s) {
+                const int dx = s / 3, dy = s - dx * 3;
+                if (s + 1 < 9) {
+                    const int dx1 = (s + 1) / 3, dy1 = (s + 1) - dx1 * 3;
+                    const int tap1 = dy1 * 3 + dx1;
+                    Wf[(s + 1) & 1][0] = sw[w_off + tap1 * 128];
+                    Wf[(s + 1) & 1][1] = sw[w_off + tap1 * 128 + 64];
+                }
+                if (dy == 0 && dx < 2) {
+#pragma unroll
+                    for (int r = 0; r < RW + 2; ++r) {
+                        P[(dx + 1) & 1][r][0] = pix_frag(r, dx + 1, 0);
+                        P[(dx + 1) & 1][r][1] = pix_frag(r, dx + 1, 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const f16x8 wh = __builtin_bit_cast(f16x8, Wf[s & 1][0]), wl = __builtin_bit_cast(f16x8, Wf[s & 1][1]);
+                if (NESR_ABL & 8) {
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) acc[r][0][0] += Wf[s & 1][0][0] + Wf[s & 1][1][0] + P[dx & 1][r + dy][0][0] + P[dx & 1][r + dy][1][0];
+                    continue;
+                }
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+                    acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][1]), acc[r][1], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+                    acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][0]), acc[r][0], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+                    acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][0]), acc[r][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        STAMP(11 + 4 * c);
+    }
+    STAMP(2);
+    if (!active) return;
+    if (NESR_ABL & 4) {
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sum += acc[r][0][e] + acc[r][1][e];
+        if (sum == 12345.678f) static_cast<float*>(a.out)[0] = sum;
+        return;
+    }
+
+    // ---- epilogue: lane = pixel column m of rows RW*wave + r; regs = 4-channel runs 8g + 4hh of this
+    // workgroup's 32 output channels (network channels 32 cg + ...)
+    const int X = x0 + m;
+    const bool xok = X < a.w_;
+    const int Xc = xok ? X : 0;
+    const int cbase = 32 * cg;
+    const uint16_t* res1 = static_cast<const uint16_t*>(a.res1);
+    const uint16_t* res2 = static_cast<const uint16_t*>(a.res2);
+    uint16_t* out = static_cast<uint16_t*>(a.out);
+    uint16_t* out2 = static_cast<uint16_t*>(a.out2);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int Y = y0 + RW * wave + r;
+        const bool valid = xok && Y < a.h;
+        const size_t pix = ((size_t)n * a.h + (Y < a.h ? Y : 0)) * a.w_ + Xc;
+        // hi half of channel c (lo: +16 elements)
+        auto at = [&](const Map& mp, int c) -> size_t { return (size_t)(c >> 4) * mp.chunk + pix * mp.pix + (c & 15); };
+        f32x4 r1[4], r2[4];
+        if (res1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) r1[g] = ld4_split(res1 + at(a.res1_map, cbase + 8 * g + 4 * hh));
+        }
+        if (res2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) r2[g] = ld4_split(res2 + at(a.res2_map, cbase + 8 * g + 4 * hh));
+        }
+        f32x4 v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float x = (acc[r][0][4 * g + q] + acc[r][1][4 * g + q]) + bs[g][q];
+                if (a.lrelu) x = x > 0.f ? x : x * 0.2f;
+                if (res1) x = __fadd_rn(__fmul_rn(x, a.s1), r1[g][q]);
+                if (res2) x = __fadd_rn(__fmul_rn(x, a.s2), r2[g][q]);
+                v[g][q] = x;
+            }
+        // widen to 8 channels per lane (permlane32_swap, see conv3x3_bf16.hip): the lower half-wave ends
+        // up with channels 16j..16j+7 of its pixel, the upper one with 16j+8..16j+15; once per plane
+        uint4 whi[2], wlo[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            uint2 eh, el, oh, ol;
+            split4(v[2 * j], eh, el);
+            split4(v[2 * j + 1], oh, ol);
+            const auto hx = __builtin_amdgcn_permlane32_swap(eh.x, oh.x, false, false);
+            const auto hy = __builtin_amdgcn_permlane32_swap(eh.y, oh.y, false, false);
+            const auto lx = __builtin_amdgcn_permlane32_swap(el.x, ol.x, false, false);
+            const auto ly = __builtin_amdgcn_permlane32_swap(el.y, ol.y, false, false);
+            whi[j] = uint4{hx[0], hy[0], hx[1], hy[1]};
+            wlo[j] = uint4{lx[0], ly[0], lx[1], ly[1]};
+        }
+        if (valid) {
+            if (out) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    uint16_t* p = out + at(a.out_map, a.out_coff + cbase + 16 * j + 8 * hh);
+                    store16(p, whi[j]);
+                    store16(p + 16, wlo[j]);
+                }
+            }
+            if (out2) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    uint16_t* p = out2 + at(a.out2_map, cbase + 16 * j + 8 * hh);
+                    store16(p, whi[j]);
+                    store16(p + 16, wlo[j]);
+                }
+            }
+            if (a.cout_real > 0 && hh == 0 && cg == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q >= a.cout_real) break;
+                    const float x = v[0][q];
+                    if (a.out_nchw) a.out_nchw[(((size_t)n * a.cout_real + q) * a.h + Y) * a.w_ + X] = x;
+                    if (a.out_u8) {
+                        float qv = fminf(fmaxf(x, 0.f), 1.f) * 255.0f;
+                        qv = a.u8_round ? rintf(qv) : truncf(qv);
+                        const int ch = a.u8_flip ? (a.cout_real - 1 - q) : q;
+                        a.out_u8[pix * a.cout_real + ch] = (uint8_t)qv;
+                    }
+                }
+            }
+        }
+    }
+    STAMP(3);
+#if NESR_ABL & 64
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(4);
+#endif
+}
+
+template <int RW, int ISLOTS>
+hipError_t launch_split(const ConvArgs& a, hipStream_t s) {
+    typedef Geo<RW> G;
+    constexpr size_t shm = (size_t)ISLOTS * G::IN_BYTES + 2 * (size_t)(W_ITEMS1 * 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x2_kernel<RW, ISLOTS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const long total = (long)((a.w_ + TW - 1) / TW) * ((a.h + G::TH - 1) / G::TH) * a.n * (a.coutp >> 5);
+    if (total <= 0) return hipSuccess;
+    if (total > 0x7fffffffL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((conv3x3_f16x2_kernel<RW, ISLOTS>), dim3((unsigned)total), dim3(G::THREADS), shm, s, a);
+    return hipGetLastError();
+}
+
+inline uint16_t f2h(float f) {
+    const _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+inline float h2f(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+
+}  // namespace
+
+#if NESR_ABL & 64
+extern "C" int nesr_debug_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n < 256 ? n : 256));
+}
+#endif
+
+size_t packed_weight_elems_f16x2(int cin_p, int coutp) { return (size_t)cin_p * 9 * coutp * 2; }
+
+// OIHW f32 -> [chunk = ci/16][cout group = o/32][tap][plane hi|lo][k half = (ci%16)/8][o%32][ci%8] halves
+void pack_weights_f16x2(const float* oihw, int cout, int cin, int cin_p, int coutp, uint16_t* dst) {
+    const size_t total = packed_weight_elems_f16x2(cin_p, coutp);
+    for (size_t i = 0; i < total; ++i) dst[i] = 0;
+    const int groups = coutp / 32;
+    for (int o = 0; o < cout; ++o)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int tap = 0; tap < 9; ++tap) {
+                float wv = oihw[((size_t)o * cin + ci) * 9 + tap];
+                wv = wv > 65504.f ? 65504.f : (wv < -65504.f ? -65504.f : wv);
+                const uint16_t hi = f2h(wv);
+                const uint16_t lo = f2h(wv - h2f(hi));
+                const int c = ci / 16, kh = (ci % 16) / 8, kk = ci % 8;
+                const size_t slab = ((size_t)c * groups + o / 32) * (size_t)(W_ITEMS1 * 8);
+                const size_t ihi = slab + ((((size_t)tap * 2 + 0) * 2 + kh) * 32 + o % 32) * 8 + kk;
+                const size_t ilo = slab + ((((size_t)tap * 2 + 1) * 2 + kh) * 32 + o % 32) * 8 + kk;
+                dst[ihi] = hi;
+                dst[ilo] = lo;
+            }
+}
+
+hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s) {
+    if (a.cin % 16 || (a.coutp != 32 && a.coutp != 64)) return hipErrorInvalidValue;
+    if ((long long)a.in_h * a.in_w >= (1ll << 26)) return hipErrorInvalidValue;   // 32-bit byte offsets inside one image chunk
+    if (a.in_map.pix != 32 || (a.out && (a.out_map.pix % 32 || a.out_coff % 16))) return hipErrorInvalidValue;
+    if ((a.out_nchw || a.out_u8) && (a.coutp != 32 || a.cout_real < 1 || a.cout_real > 4)) return hipErrorInvalidValue;
+    // rows per wave: 1 (8x32-px tiles, two workgroups per CU) until 16x32-px tiles (2 rows per wave, one
+    // workgroup per CU: half the weight and halo traffic per pixel) fill the chip several times over
+    static const int force = [] { const char* e = getenv("NESR_SPLIT_ROWS"); return e ? atoi(e) : 0; }();
+    const long t2 = (long)((a.w_ + TW - 1) / TW) * ((a.h + 15) / 16) * a.n * (a.coutp >> 5);
+    const bool rw2 = force ? force == 2 : t2 >= 2048;
+    return rw2 ? launch_split<RW_L, 2>(a, s) : launch_split<RW_S, 2>(a, s);
+}
+
+}  // namespace nesr

@@ -74,6 +74,9 @@ __device__ __forceinline__ void store_fm(float* p, f32x4 v) {
 #endif
 }
 
+#ifndef NESR_ABL
+#define NESR_ABL 0   // timing ablations (tools/ablate.sh): 1 no MFMA, 2 no input transform, 4 no input staging, 8 no weight DMA, 16 no epilogue
+#endif
 template <int NT, int STAGES, int CW>
 __global__ __launch_bounds__(128 * CW, 2) void conv3x3_wino_f32_kernel(ConvArgs a) {
     constexpr int THREADS = 128 * CW;
@@ -234,8 +237,8 @@ __global__ __launch_bounds__(128 * CW, 2) void conv3x3_wino_f32_kernel(ConvArgs 
     }
     for (int c = 0; c < nchunks; ++c) {
         const int cn = c + STAGES - 1 < nchunks ? c + STAGES - 1 : nchunks - 1;
-        dma_weights(cn, s_fill);    // slot s_fill was last read in iteration c-1 (barrier passed)
-        load_chunk(cn);
+        if (!(NESR_ABL & 8)) dma_weights(cn, s_fill);    // slot s_fill was last read in iteration c-1 (barrier passed)
+        if (!(NESR_ABL & 4)) load_chunk(cn);
         const char* st = smem + s_cur * STAGE_BYTES;
         const char* sn = smem + s_nxt * STAGE_BYTES;
         f32x2 dn[4][4], tn[4][4], Vn[16];
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(128 * CW, 2) void conv3x3_wino_f32_kernel(ConvArgs 
                 if constexpr (NT == 2) { ua[nxt] = U(g + 1, 0); ub[nxt] = U(g + 1, 1); }
                 else { ua[nxt] = U(2 * g + 2, 0); ub[nxt] = U(2 * g + 3, 0); }
             }
-            if constexpr (PIPE) {   // a slice of the next chunk's input transform (GROUPS == 8 here)
+            if constexpr (PIPE && !(NESR_ABL & 2)) {   // a slice of the next chunk's input transform (GROUPS == 8 here)
                 if (g < 4) read_row(sn, g, dn);
                 else if (g == 4) { bt_cols(dn, tn, 0); bt_cols(dn, tn, 1); }
                 else if (g == 5) { bt_cols(dn, tn, 2); bt_cols(dn, tn, 3); }
@@ -267,7 +270,9 @@ __global__ __launch_bounds__(128 * CW, 2) void conv3x3_wino_f32_kernel(ConvArgs 
                 else { b_row(tn, Vn, 2); b_row(tn, Vn, 3); }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (NT == 2) {
+            if constexpr (NESR_ABL & 1) {
+                acc[0][g][0] += ua[cur][0] + ub[cur][0] + V[g][0];
+            } else if constexpr (NT == 2) {
                 acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[cur][0], V[g][0], acc[0][g], 0, 0, 0);
                 acc[1][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ub[cur][0], V[g][0], acc[1][g], 0, 0, 0);
                 acc[0][g] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[cur][1], V[g][1], acc[0][g], 0, 0, 0);
@@ -282,13 +287,15 @@ __global__ __launch_bounds__(128 * CW, 2) void conv3x3_wino_f32_kernel(ConvArgs 
             __builtin_amdgcn_sched_barrier(0);
         }
         }
-        if constexpr (PIPE) {
+        if constexpr (PIPE && !(NESR_ABL & 2)) {
             if (!idle) {
 #pragma unroll
                 for (int p = 0; p < 16; ++p) V[p] = Vn[p];
             }
         }
-        store_chunk(s_fill);
+        // (carrying the staged chunk in registers across a whole iteration, so that nothing issued in an
+        // iteration is waited for in it, measured no gain: the loop is not latency-bound)
+        if (!(NESR_ABL & 4)) store_chunk(s_fill);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's weight DMA (issued a whole chunk ago) has landed
         __syncthreads();
         s_cur = s_cur == STAGES - 1 ? 0 : s_cur + 1;
@@ -299,6 +306,15 @@ __global__ __launch_bounds__(128 * CW, 2) void conv3x3_wino_f32_kernel(ConvArgs 
     // ---- output transform + fused epilogue.  C/D map of 16x16x4: col = lane&15 (tile), rows 4*(lane>>4)+r
     // (couts); this lane: tile (tr, tc), channels 16*(NT*cgw + t) + 4*kq .. +3.
     if (idle) return;
+    if (NESR_ABL & 16) {
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int p = 0; p < 16; ++p) sum += acc[t][p][0] + acc[t][p][1] + acc[t][p][2] + acc[t][p][3];
+        if (sum == 12345.678f) static_cast<float*>(a.out)[0] = sum;
+        return;
+    }
     const float* res1 = static_cast<const float*>(a.res1);
     const float* res2 = static_cast<const float*>(a.res2);
     float* out = static_cast<float*>(a.out);

@@ -71,7 +71,9 @@ struct nesr_ctx {
     int64_t timed_launches = 0;
     double timed_flops = 0.0;
 
-    size_t esize() const { return dtype == NESR_DTYPE_BF16 ? 2 : 4; }
+    size_t esize() const { return dtype == NESR_DTYPE_BF16 ? 2 : 4; }   // bytes per stored activation value
+    // activation layout / kernel family: 0 f32 NHWC, 1 bf16 blocked, 2 f16 hi|lo blocked (PackArgs::bf16)
+    int kind() const { return dtype == NESR_DTYPE_BF16 ? 1 : (dtype == NESR_DTYPE_F32_SPLIT ? 2 : 0); }
     int ct() const { return nf + 4 * gc; }  // channels of a dense-block buffer
     int ufac() const { return unshuffle > 1 ? unshuffle : 1; }
 };
@@ -129,6 +131,7 @@ int ensure_ws(nesr_ctx* c, size_t bytes) {
 
 hipError_t launch_conv(const nesr_ctx* c, const ConvArgs& a, hipStream_t s, const Layer* L = nullptr) {
     if (c->dtype == NESR_DTYPE_BF16) return launch_conv3x3_bf16(a, s);
+    if (c->dtype == NESR_DTYPE_F32_SPLIT) return launch_conv3x3_f16x2(a, s);
     if (c->winograd && L && L->d_ww && (!(a.out_nchw || a.out_u8) || (a.cout_real >= 1 && a.cout_real <= 4 && a.coutp == 32))) {
         ConvArgs w = a;
         w.w = L->d_ww;
@@ -155,10 +158,12 @@ ConvArgs base_args(const nesr_ctx* c, const Layer& L, int N, int h, int w) {
     return a;
 }
 
-// f32: NHWC (pix = channels of the buffer, chunk = 8).  bf16: channel-blocked [C/16][pixels][16].
-Map make_map(bool bf16, int channels, size_t pixels) {
+// kind 0 (f32): NHWC (pix = channels of the buffer, chunk = 8).  kind 1 (bf16): channel-blocked
+// [C/16][pixels][16].  kind 2 (f16 pairs): [C/16][pixels][16 hi | 16 lo], in 2-byte units.
+Map make_map(int kind, int channels, size_t pixels) {
     Map m;
-    if (bf16) { m.pix = 16; m.chunk = (long long)pixels * 16; }
+    if (kind == 2) { m.pix = 32; m.chunk = (long long)pixels * 32; }
+    else if (kind == 1) { m.pix = 16; m.chunk = (long long)pixels * 16; }
     else { m.pix = channels; m.chunk = 8; }
     return m;
 }
@@ -182,7 +187,7 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
     if (rc) return rc;
     char* ws = c->ws;
     const int nf = c->nf, gc = c->gc, ct = c->ct();
-    const bool bf = c->dtype == NESR_DTYPE_BF16;
+    const int bf = c->kind();
 
     PackArgs p;
     std::memset(&p, 0, sizeof(p));
@@ -240,7 +245,7 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
         t.progress = sync + 64;
         t.abort_flag = sync;
         t.zeros = c->d_weights;
-        HIP_TRY(launch_trunk_persist(t, bf, s));
+        HIP_TRY(launch_trunk_persist(t, bf == 1, s));
         c->last_sync = sync;
         if (c->timing)
             for (int i = 0; i < c->nb * 15; ++i) c->timed_flops += conv_flops(c->layers[1 + i], px);
@@ -342,8 +347,8 @@ int nesr_create(nesr_ctx** out, int device_id, int conv_first_in_ch, int unshuff
     if (num_feat != 32 && num_feat != 64) return fail(NESR_ERR_ARG, "num_feat must be 32 or 64 (reference uses 64)");
     if (num_grow_ch != 32) return fail(NESR_ERR_ARG, "num_grow_ch must be 32 (reference uses 32)");
     if (num_block < 0 || num_out_ch <= 0 || num_out_ch > 32) return fail(NESR_ERR_ARG, "bad num_block / num_out_ch");
-    if (dtype != NESR_DTYPE_F32 && dtype != NESR_DTYPE_BF16 && dtype != NESR_DTYPE_F32_WINOGRAD)
-        return fail(NESR_ERR_ARG, "dtype must be 0 (f32), 1 (bf16) or 2 (f32, Winograd)");
+    if (dtype != NESR_DTYPE_F32 && dtype != NESR_DTYPE_BF16 && dtype != NESR_DTYPE_F32_WINOGRAD && dtype != NESR_DTYPE_F32_SPLIT)
+        return fail(NESR_ERR_ARG, "dtype must be 0 (f32 direct), 1 (bf16), 2 (f32 Winograd) or 3 (f32 as f16 pairs)");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device_id < 0 || device_id >= ndev) return fail(NESR_ERR_ARG, "no such device " + std::to_string(device_id));
@@ -357,11 +362,14 @@ int nesr_create(nesr_ctx** out, int device_id, int conv_first_in_ch, int unshuff
     c->nout = num_out_ch;
     c->winograd = dtype == NESR_DTYPE_F32_WINOGRAD;
     if (const char* e = getenv("NESR_F32_ALGO")) {   // override for A/B timing: direct | winograd
-        if (dtype != NESR_DTYPE_BF16) c->winograd = e[0] == 'w';
+        if (dtype != NESR_DTYPE_BF16) {
+            c->winograd = e[0] == 'w';
+            dtype = e[0] == 's' ? NESR_DTYPE_F32_SPLIT : (e[0] == 'w' ? NESR_DTYPE_F32_WINOGRAD : NESR_DTYPE_F32);
+        }
     }
     if (dtype == NESR_DTYPE_F32_WINOGRAD) dtype = NESR_DTYPE_F32;
     c->dtype = dtype;
-    c->kgroup = dtype == NESR_DTYPE_BF16 ? 16 : 8;
+    c->kgroup = (dtype == NESR_DTYPE_BF16 || dtype == NESR_DTYPE_F32_SPLIT) ? 16 : 8;
     if (const char* e = getenv("NESR_TRUNK")) c->trunk_mode = e[0] == 'l' ? 1 : (e[0] == 'p' ? 2 : 0);
     auto add = [&](const std::string& name, int cin, int cout) {
         Layer L;
@@ -428,14 +436,16 @@ int nesr_finalize_weights(nesr_ctx* c) {
     if (nmiss) return fail(NESR_ERR_STATE, "Missing key(s) in state_dict (" + std::to_string(nmiss) + "):" + missing);
     HIP_TRY(hipSetDevice(c->device));
     const bool bf = c->dtype == NESR_DTYPE_BF16;
+    const bool sp = c->dtype == NESR_DTYPE_F32_SPLIT;
     size_t total = 256;   // leading zero page
     std::vector<size_t> woff(c->layers.size()), boff(c->layers.size()), wwoff(c->layers.size(), 0);
     const size_t last = c->layers.size() - 1;
     for (size_t i = 0; i < c->layers.size(); ++i) {
         const Layer& L = c->layers[i];
-        const size_t we = bf ? packed_weight_elems_bf16(L.cin_p, L.cout_p) : packed_weight_elems_f32(L.cin_p, L.cout_p);
+        const size_t we = sp ? packed_weight_elems_f16x2(L.cin_p, L.cout_p)
+                             : (bf ? packed_weight_elems_bf16(L.cin_p, L.cout_p) : packed_weight_elems_f32(L.cin_p, L.cout_p));
         woff[i] = total;
-        total = align_up(total + we * (bf ? 2 : 4), 256);
+        total = align_up(total + we * ((bf || sp) ? 2 : 4), 256);
         boff[i] = total;
         total = align_up(total + (size_t)L.cout_p * 4, 256);
         (void)last;
@@ -447,7 +457,9 @@ int nesr_finalize_weights(nesr_ctx* c) {
     std::vector<char> host(total, 0);
     for (size_t i = 0; i < c->layers.size(); ++i) {
         const Layer& L = c->layers[i];
-        if (bf)
+        if (sp)
+            pack_weights_f16x2(L.w.data(), L.cout, L.cin, L.cin_p, L.cout_p, reinterpret_cast<uint16_t*>(host.data() + woff[i]));
+        else if (bf)
             pack_weights_bf16(L.w.data(), L.cout, L.cin, L.cin_p, L.cout_p, reinterpret_cast<uint16_t*>(host.data() + woff[i]));
         else
             pack_weights_f32(L.w.data(), L.cout, L.cin, L.cin_p, L.cout_p, reinterpret_cast<float*>(host.data() + woff[i]));
@@ -629,19 +641,24 @@ int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, in
                  const float* b_host, int Cout, int lrelu, int upsample, void* y_dev, void* stream) {
     if (!x_dev || !w_host || !b_host || !y_dev) return fail(NESR_ERR_ARG, "null argument");
     if (N <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cout > 64) return fail(NESR_ERR_ARG, "bad shape (Cout <= 64)");
-    if (dtype != NESR_DTYPE_F32 && dtype != NESR_DTYPE_BF16 && dtype != NESR_DTYPE_F32_WINOGRAD) return fail(NESR_ERR_ARG, "bad dtype");
+    if (dtype != NESR_DTYPE_F32 && dtype != NESR_DTYPE_BF16 && dtype != NESR_DTYPE_F32_WINOGRAD && dtype != NESR_DTYPE_F32_SPLIT)
+        return fail(NESR_ERR_ARG, "bad dtype");
     const bool wino = dtype == NESR_DTYPE_F32_WINOGRAD;
+    const bool sp = dtype == NESR_DTYPE_F32_SPLIT;
+    const int kind = sp ? 2 : (dtype == NESR_DTYPE_BF16 ? 1 : 0);
     HIP_TRY(hipSetDevice(device_id));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const bool bf = dtype == NESR_DTYPE_BF16;
     const size_t es = bf ? 2 : 4;
-    const int cin_p = round_up(Cin, bf ? 16 : 8), cout_p = round_up(Cout, 32);
+    const int cin_p = round_up(Cin, (bf || sp) ? 16 : 8), cout_p = round_up(Cout, 32);
     const int up = upsample ? 1 : 0;
     const int ho = H << up, wo = W << up;
-    const size_t we = bf ? packed_weight_elems_bf16(cin_p, cout_p)
+    const size_t we = sp ? packed_weight_elems_f16x2(cin_p, cout_p) / 2 : bf ? packed_weight_elems_bf16(cin_p, cout_p)
                          : (wino ? packed_weight_elems_wino_f32(cin_p, cout_p) : packed_weight_elems_f32(cin_p, cout_p));
     std::vector<char> hw(we * es);
-    if (bf)
+    if (sp)
+        pack_weights_f16x2(w_host, Cout, Cin, cin_p, cout_p, reinterpret_cast<uint16_t*>(hw.data()));
+    else if (bf)
         pack_weights_bf16(w_host, Cout, Cin, cin_p, cout_p, reinterpret_cast<uint16_t*>(hw.data()));
     else if (wino)
         pack_weights_wino_f32(w_host, Cout, Cin, cin_p, cout_p, reinterpret_cast<float*>(hw.data()));
@@ -662,8 +679,8 @@ int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, in
     HIP_TRY(hipMemcpy(d_b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
     PackArgs p;
     std::memset(&p, 0, sizeof(p));
-    const Map mi = make_map(bf, cin_p, (size_t)N * H * W), mo = make_map(bf, cout_p, (size_t)N * ho * wo);
-    p.src = x_dev; p.n = N; p.c = Cin; p.hin = H; p.win = W; p.unshuffle = 1; p.dst = d_in; p.dst_map = mi; p.cp = cin_p; p.bf16 = bf;
+    const Map mi = make_map(kind, cin_p, (size_t)N * H * W), mo = make_map(kind, cout_p, (size_t)N * ho * wo);
+    p.src = x_dev; p.n = N; p.c = Cin; p.hin = H; p.win = W; p.unshuffle = 1; p.dst = d_in; p.dst_map = mi; p.cp = cin_p; p.bf16 = kind;
     HIP_TRY(launch_pack_input(p, s));
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -673,8 +690,8 @@ int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, in
     a.out = d_out; a.out_map = mo; a.out_coff = 0;
     a.lrelu = lrelu ? 1 : 0; a.s1 = a.s2 = 1.f;
     a.zeros = d_zero;
-    HIP_TRY(bf ? launch_conv3x3_bf16(a, s) : (wino ? launch_conv3x3_wino_f32(a, s) : launch_conv3x3_f32(a, s)));
-    HIP_TRY(launch_nhwc_to_nchw(d_out, bf, mo, N, Cout, ho, wo, static_cast<float*>(y_dev), s));
+    HIP_TRY(sp ? launch_conv3x3_f16x2(a, s) : bf ? launch_conv3x3_bf16(a, s) : (wino ? launch_conv3x3_wino_f32(a, s) : launch_conv3x3_f32(a, s)));
+    HIP_TRY(launch_nhwc_to_nchw(d_out, kind, mo, N, Cout, ho, wo, static_cast<float*>(y_dev), s));
     HIP_TRY(hipStreamSynchronize(s));
     (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_zero);
     return NESR_OK;

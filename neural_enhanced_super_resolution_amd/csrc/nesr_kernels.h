@@ -74,6 +74,13 @@ hipError_t launch_conv3x3_bf16_xl(const ConvArgs& a, hipStream_t s);    // conv3
 size_t packed_weight_elems_bf16(int cin_p, int coutp);
 void pack_weights_bf16(const float* oihw, int cout, int cin, int cin_p, int coutp, uint16_t* dst);
 
+// f32 path on the f16 matrix cores (conv3x3_f16x2.hip): operands as exact-sum (hi, lo) half pairs, three
+// MFMAs per product, f32 accumulation.  Activations: channel-blocked [C/16][pixels][16 hi | 16 lo]
+// (Map in 2-byte units: pix = 32, chunk = pixels * 32).
+hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s);
+size_t packed_weight_elems_f16x2(int cin_p, int coutp);   // in 2-byte units
+void pack_weights_f16x2(const float* oihw, int cout, int cin, int cin_p, int coutp, uint16_t* dst);
+
 // Persistent trunk (conv3x3_mfma.hip): all dense-block convs of the 23 RRDBs in ONE cooperative
 // launch.  Workgroups keep their tiles from layer to layer and synchronise with their 8
 // neighbouring tiles only (per-tile progress counters, agent-scope release/acquire), instead of 345
@@ -108,11 +115,11 @@ struct PackArgs {
     void* dst;           // feature map with cp channels (zero padded), addressed through dst_map
     Map dst_map;
     int cp;
-    int bf16;            // destination element type (KG = 16) else f32 (KG = 8)
+    int bf16;            // destination layout: 0 f32 NHWC (KG = 8), 1 bf16 blocked (KG = 16), 2 f16 hi|lo blocked (KG = 16)
 };
 hipError_t launch_pack_input(const PackArgs& a, hipStream_t s);
 
 // feature map (channels [0,c)) -> planar f32 NCHW; used by the single-layer test hook
-hipError_t launch_nhwc_to_nchw(const void* src, int bf16, Map map, int n, int c, int h, int w, float* dst, hipStream_t s);
+hipError_t launch_nhwc_to_nchw(const void* src, int kind /* as PackArgs::bf16 */, Map map, int n, int c, int h, int w, float* dst, hipStream_t s);
 
 }  // namespace nesr

@@ -18,6 +18,17 @@ __device__ inline uint16_t f2bf(float f) {
     return *reinterpret_cast<uint16_t*>(&b);
 }
 __device__ inline float bf2f(uint16_t u) { return __uint_as_float(((unsigned)u) << 16); }
+// f32 -> exact-sum (hi, lo) half pair of the f16x2 path (conv3x3_f16x2.hip)
+__device__ inline void f2hl(float f, uint16_t& hi, uint16_t& lo) {
+    const float x = fminf(fmaxf(f, -65504.f), 65504.f);
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    hi = __builtin_bit_cast(uint16_t, h);
+    lo = __builtin_bit_cast(uint16_t, l);
+}
+__device__ inline float hl2f(uint16_t hi, uint16_t lo) {
+    return (float)__builtin_bit_cast(_Float16, hi) + (float)__builtin_bit_cast(_Float16, lo);
+}
 
 __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
     const int s = a.unshuffle;
@@ -45,7 +56,12 @@ __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
             }
             const int kg = a.bf16 ? 16 : 8;
             const size_t idx = (size_t)(co / kg) * a.dst_map.chunk + pix * a.dst_map.pix + (co % kg);
-            if (a.bf16)
+            if (a.bf16 == 2) {
+                uint16_t hi, lo;
+                f2hl(v, hi, lo);
+                static_cast<uint16_t*>(a.dst)[idx] = hi;
+                static_cast<uint16_t*>(a.dst)[idx + 16] = lo;
+            } else if (a.bf16)
                 static_cast<uint16_t*>(a.dst)[idx] = f2bf(v);
             else
                 static_cast<float*>(a.dst)[idx] = v;
@@ -63,7 +79,10 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* src, int 
         const size_t pix = ((size_t)nn * h + y) * w + x;
         const int kg = bf16 ? 16 : 8;
         const size_t idx = (size_t)(ch / kg) * map.chunk + pix * map.pix + (ch % kg);
-        dst[i] = bf16 ? bf2f(static_cast<const uint16_t*>(src)[idx]) : static_cast<const float*>(src)[idx];
+        if (bf16 == 2)
+            dst[i] = hl2f(static_cast<const uint16_t*>(src)[idx], static_cast<const uint16_t*>(src)[idx + 16]);
+        else
+            dst[i] = bf16 ? bf2f(static_cast<const uint16_t*>(src)[idx]) : static_cast<const float*>(src)[idx];
     }
 }
 

@@ -151,6 +151,8 @@ class RRDBNet(nn.Module):
     def _dtype_code(self):
         if self.compute_dtype in ("f32", "fp32", torch.float32, "f32-winograd", "f32w", "winograd"):
             return _lib.DTYPE_F32_WINOGRAD      # default f32 algorithm: Winograd F(2x2,3x3) for the feature-map convs
+        if self.compute_dtype in ("f32-split", "f32-f16x2", "split"):
+            return _lib.DTYPE_F32_SPLIT         # f32 on the f16 matrix cores: (hi, lo) half pairs, 3 MFMAs per product
         if self.compute_dtype in ("f32-direct", "direct"):
             return _lib.DTYPE_F32               # direct implicit GEMM everywhere (bitwise a k-ordered fmaf chain)
         if self.compute_dtype in ("bf16", torch.bfloat16, "half", torch.float16):
@@ -325,7 +327,7 @@ def conv3x3(x, weight, bias, lrelu=False, upsample=False, dtype="f32"):
     index = x.device.index if x.device.index is not None else torch.cuda.current_device()
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        code = {"bf16": _lib.DTYPE_BF16, "f32-winograd": _lib.DTYPE_F32_WINOGRAD, "f32": _lib.DTYPE_F32,
+        code = {"bf16": _lib.DTYPE_BF16, "f32-winograd": _lib.DTYPE_F32_WINOGRAD, "f32": _lib.DTYPE_F32, "f32-split": _lib.DTYPE_F32_SPLIT,
                 "f32-direct": _lib.DTYPE_F32}[dtype]
         _lib.check(lib.nesr_conv3x3(index, code,
                                     ctypes.c_void_p(x.data_ptr()), n, cin, h, w, ctypes.c_void_p(wt.data_ptr()),

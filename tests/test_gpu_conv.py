@@ -169,3 +169,70 @@ def test_winograd_vs_direct_random_shapes(cuda_device):
         assert a.shape == c.shape
         tol = WINO_TOL * max(1.0, a.abs().max().item())
         assert (a - c).abs().max().item() < tol, (n, cin, cout, h, w, up, lrelu)
+
+
+# ---------------------------------------------------------------- f32 on the f16 matrix cores (f16 pairs)
+SPLIT_TOL = 2e-5   # relative to max|ref|: operands carry 22-23 bits, products lose w_lo*x_lo (2^-22)
+
+
+@pytest.mark.parametrize("cin,cout", SHAPES)
+@pytest.mark.parametrize("hw", [(24, 40), (1, 1), (7, 5), (9, 17), (33, 47), (16, 130)])
+def test_conv3x3_f32_split_matches_torch(cuda_device, cin, cout, hw):
+    from neural_enhanced_super_resolution_amd import conv3x3
+    x, w, b = _case(cin, cout, hw[0], hw[1], seed=cin * 11 + cout + hw[1], n=2)
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2)
+    got = conv3x3(x.to(cuda_device), w, b, lrelu=True, dtype="f32-split").cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < SPLIT_TOL * max(1.0, ref.abs().max().item())
+
+
+def test_conv3x3_f32_split_one_hot_taps_upsample_and_small_values(cuda_device):
+    from neural_enhanced_super_resolution_amd import conv3x3
+    cin, cout = 16, 32
+    x = (torch.arange(cin * 10 * 12, dtype=torch.float32).reshape(1, cin, 10, 12) * 3) % 127
+    for tap in range(9):
+        w = torch.zeros(cout, cin, 3, 3)
+        for o in range(cout):
+            w[o, (o * 5 + tap) % cin, tap // 3, tap % 3] = 1.0
+        b = torch.arange(cout, dtype=torch.float32)
+        ref = F.conv2d(x, w, b, padding=1)
+        got = conv3x3(x.to(cuda_device), w, b, dtype="f32-split").cpu()
+        assert torch.equal(got, ref), f"tap {tap}"      # small integers are exact in every plane
+    xs, ws, bs = _case(64, 64, 13, 21, seed=5)
+    ref = F.conv2d(F.interpolate(xs, scale_factor=2, mode="nearest"), ws, bs, padding=1)
+    got = conv3x3(xs.to(cuda_device), ws, bs, upsample=True, dtype="f32-split").cpu()
+    assert (got - ref).abs().max().item() < SPLIT_TOL * max(1.0, ref.abs().max().item())
+    # values whose lo halves are f16 subnormals (|x| ~ 1e-3): the matrix core must not flush them
+    xt, wt, bt = _case(64, 32, 20, 36, seed=9)
+    xt, bt = xt * 1e-3, bt * 0
+    ref = F.conv2d(xt, wt, bt, padding=1)
+    got = conv3x3(xt.to(cuda_device), wt, bt, dtype="f32-split").cpu()
+    assert (got - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
+def test_conv3x3_f32_split_big_tile_variant(cuda_device):
+    """>= 2048 tiles of 16x32 px selects the 4-rows-per-wave geometry (one workgroup per CU)."""
+    from neural_enhanced_super_resolution_amd import conv3x3
+    x, w, b = _case(64, 64, 500, 509, seed=77, n=2)
+    ref = F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2)
+    got = conv3x3(x.to(cuda_device), w, b, lrelu=True, dtype="f32-split").cpu()
+    assert (got - ref).abs().max().item() < SPLIT_TOL * max(1.0, ref.abs().max().item())
+
+
+def test_split_vs_direct_random_shapes(cuda_device):
+    from neural_enhanced_super_resolution_amd import conv3x3
+    rng = np.random.default_rng(321)
+    for _ in range(24):
+        n = int(rng.integers(1, 4))
+        h, w = int(rng.integers(1, 41)), int(rng.integers(1, 80))
+        cin = int(rng.choice([3, 8, 12, 16, 64, 96, 192]))
+        cout = int(rng.choice([3, 32, 64]))
+        up = bool(rng.integers(0, 2)) and h * w < 400
+        lrelu = bool(rng.integers(0, 2))
+        x, wt, b = _case(cin, cout, h, w, seed=int(rng.integers(1 << 30)), n=n)
+        xd = x.to(cuda_device)
+        a = conv3x3(xd, wt, b, lrelu=lrelu, upsample=up, dtype="f32-direct").cpu()
+        c = conv3x3(xd, wt, b, lrelu=lrelu, upsample=up, dtype="f32-split").cpu()
+        assert a.shape == c.shape
+        tol = SPLIT_TOL * max(1.0, a.abs().max().item())
+        assert (a - c).abs().max().item() < tol, (n, cin, cout, h, w, up, lrelu)

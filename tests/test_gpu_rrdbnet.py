@@ -158,3 +158,34 @@ def test_winograd_mininet_modes(cuda_device, num_in_ch, scale):
     x = torch.rand(2, num_in_ch, 34, 46, generator=torch.Generator().manual_seed(7))
     err = (ours(x.to(cuda_device)).cpu() - ref(x)).abs().max().item()
     assert err < 1e-4, err
+
+
+def test_split_full_depth_within_tolerance(cuda_device):
+    """f32 on the f16 matrix cores (operands as (hi, lo) half pairs, 3 MFMAs per product): full 23-block
+    x2plus net vs the oracle.  North-star tolerance 1e-3; measured ~3e-6 (same class as the other f32 forms)."""
+    ours, ref = _pair(3, 2, num_block=23, seed=0, compute_dtype="f32-split")
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(11))
+    want = ref(x)
+    got = ours(x.to(cuda_device)).cpu()
+    err = (got - want).abs().max().item()
+    print("f16-pair full-depth x2plus 64x64 max abs err", err)
+    assert err < TOL_F32, err
+    assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("num_in_ch,scale", MODES)
+def test_split_mininet_modes(cuda_device, num_in_ch, scale):
+    ours, ref = _pair(num_in_ch, scale, num_block=2, seed=3, compute_dtype="f32-split")
+    x = torch.rand(2, num_in_ch, 34, 46, generator=torch.Generator().manual_seed(7))
+    err = (ours(x.to(cuda_device)).cpu() - ref(x)).abs().max().item()
+    assert err < 2e-5, err
+
+
+def test_split_big_frame_and_batch(cuda_device):
+    """Batch large enough for the 16x32-px tile geometry in the upsampler convs; batch elements independent."""
+    ours, ref = _pair(3, 2, num_block=1, seed=5, compute_dtype="f32-split")
+    x = torch.rand(3, 3, 520, 532, generator=torch.Generator().manual_seed(2))
+    got = ours(x.to(cuda_device)).cpu()
+    want = ref(x[1:2])
+    assert (got[1:2] - want).abs().max().item() < 2e-5
+    assert torch.equal(ours(x[2:3].to(cuda_device)).cpu(), got[2:3])

@@ -2,7 +2,7 @@
 """In-process A/B timing of two builds of libnesr_hip.so (cdna_hip_programming.md rule 24: perf
 deltas come from interleaved rounds in ONE process on ONE device).
 
-    tools/ab.py A.so B.so [--dtype f32|bf16] [--hw 512] [--batch 1] [--rounds 12] [--env-b K=V,K2=V2]
+    tools/ab.py A.so B.so [--dtype direct|bf16|wino|split] [--dtype-b ...] [--hw 512] [--batch 1] [--rounds 12] [--env-b K=V,K2=V2]
 """
 import argparse
 import ctypes
@@ -44,7 +44,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("a")
     ap.add_argument("b")
-    ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--dtype", default="wino")
+    ap.add_argument("--dtype-b", default=None)
     ap.add_argument("--hw", type=int, default=512)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--rounds", type=int, default=12)
@@ -52,7 +53,8 @@ def main():
     ap.add_argument("--env-a", default="")
     ap.add_argument("--env-b", default="")
     args = ap.parse_args()
-    dt = 1 if args.dtype == "bf16" else 0
+    codes = {"f32": 0, "direct": 0, "bf16": 1, "wino": 2, "split": 3}
+    dts = [codes[args.dtype], codes[args.dtype_b or args.dtype]]
     sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=2)
     x = torch.rand(args.batch, 3, args.hw, args.hw, device="cuda")
     y = [torch.empty(args.batch, 3, 2 * args.hw, 2 * args.hw, device="cuda") for _ in range(2)]
@@ -73,7 +75,7 @@ def main():
             os.environ[k] = v
         lib = load(os.path.abspath(path))
         libs.append(lib)
-        ctxs.append(make_ctx(lib, sd, dt))
+        ctxs.append(make_ctx(lib, sd, dts[i]))
         run(i)
         torch.cuda.synchronize()
         for k, _ in kvs:
@@ -83,6 +85,7 @@ def main():
         run(i)
     torch.cuda.synchronize()
     same = torch.equal(y[0], y[1])
+    maxdiff = float((y[0] - y[1]).abs().max())
     times = [[], []]
     for r in range(args.rounds):
         for i in ((0, 1) if r % 2 == 0 else (1, 0)):
@@ -95,7 +98,7 @@ def main():
     for i, name in enumerate((args.a, args.b)):
         t = times[i]
         print(f"{'AB'[i]} {os.path.basename(name):24s} median {statistics.median(t):8.3f} ms   min {min(t):8.3f}   max {max(t):8.3f}")
-    print(f"B/A median ratio {statistics.median(times[1]) / statistics.median(times[0]):.4f}   outputs bitwise equal: {same}")
+    print(f"B/A median ratio {statistics.median(times[1]) / statistics.median(times[0]):.4f}   outputs bitwise equal: {same} (max abs diff {maxdiff:.3e})")
 
 
 if __name__ == "__main__":
