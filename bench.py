@@ -26,7 +26,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md, chip-level table)
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md, chip-level table)
+# f32 workloads: which conv algorithm (RRDBNet compute_dtype); --f32-algo or NESR_F32_ALGO=split|winograd|direct
+F32_ALGOS = {
+    "split": dict(compute_dtype="f32", mfma="f16", executed_per_algorithmic=3.0,
+                  dtype="f32 (operands as f16 hi+lo pairs, 3 f16 MFMAs per product, f32 accumulate)",
+                  algorithm="direct implicit GEMM, v_mfma_f32_32x32x16_f16 x3 (hi*hi + hi*lo + lo*hi)"),
+    "winograd": dict(compute_dtype="f32-winograd", mfma="f32", executed_per_algorithmic=1 / 2.25, dtype="f32",
+                     algorithm="winograd F(2x2,3x3), v_mfma_f32_16x16x4_f32"),
+    "direct": dict(compute_dtype="f32-direct", mfma="f32", executed_per_algorithmic=1.0, dtype="f32",
+                   algorithm="direct implicit GEMM, v_mfma_f32_32x32x2_f32"),
+}
 
 WORKLOADS = {
     # name: (H, W, num_in_ch, upstream scale, netscale, dtype, tile, tile_pad)
@@ -100,6 +110,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-crop", type=int, default=512, help="side of the crop the CPU oracle is timed on (0 = skip)")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--f32-algo", default=None, choices=["split", "winograd", "direct"],
+                    help="conv algorithm of the fp32 workloads (default split: f16 hi+lo operand pairs)")
     args = ap.parse_args()
 
     import numpy as np
@@ -126,7 +138,12 @@ def main():
     netscale = {2: 2, 1: 1}.get(scale, 4)
     sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=scale)
     frame = synthetic_frame(wl["h"], wl["w"], seed=rank)            # uint8 HWC BGR, one per rank
-    net = RRDBNet(3, 3, scale=scale, compute_dtype=dtype)
+    algo = None
+    if dtype == "f32":
+        key = (args.f32_algo or os.environ.get("NESR_F32_ALGO") or "split").lower()
+        algo = F32_ALGOS[{"s": "split", "w": "winograd", "d": "direct"}[key[0]]]
+        os.environ.pop("NESR_F32_ALGO", None)   # the choice travels as compute_dtype
+    net = RRDBNet(3, 3, scale=scale, compute_dtype=algo["compute_dtype"] if algo else dtype)
     up = RealESRGANer(scale=netscale, model_path={"params_ema": sd}, model=net, tile=wl["tile"], tile_pad=wl["tile_pad"],
                       pre_pad=0, half=False, device=dev)
     model = up.model
@@ -187,7 +204,7 @@ def main():
         "value": round(value, 3), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
         "scaling": "strong" if sharded_frame else "weak",
-        "vs_baseline": None, "dtype": dtype, "data": "synthetic (seeded frames, seeded random-init weights)",
+        "vs_baseline": None, "dtype": algo["dtype"] if algo else dtype, "data": "synthetic (seeded frames, seeded random-init weights)",
         "config": {"workload": f"{args.workload}: {wl['desc']}",
                    "frames_per_step": frames_per_step,
                    "partition": ("tiles of the 512/10 grid sharded over ranks, RCCL p2p overlap rows, gather on rank 0" if sharded_frame
@@ -202,19 +219,19 @@ def main():
         # concurrent streams: per-stream event brackets overlap, so divide the trunk FLOPs by the wall
         # time of the timed region instead (includes the non-trunk kernels: a lower bound)
         achieved = k_flops / ((elapsed if multi_stream else k_ms * 1e-3)) / 1e12
-        peak = PEAK_TFLOPS[dtype]
-        # f32: the 3x3 convs run as Winograd F(2x2,3x3) -- 16 MFMA-MACs per 2x2 outputs instead of 36, so the
-        # matrix cores execute algorithmic/2.25 FLOPs; `achieved`/`frac` use the ALGORITHMIC (direct-conv)
-        # FLOPs as the contract asks, `executed_frac` is the matrix-core utilisation of what actually runs.
-        wino = dtype == "f32" and os.environ.get("NESR_F32_ALGO", "w")[0] == "w"
+        # `achieved` / `frac` use the ALGORITHMIC (direct-conv) FLOPs as the contract asks, against the dense
+        # peak of the MFMA type that runs; `executed_frac` is the matrix-core utilisation of what actually
+        # executes: 3 f16 MFMA-FLOPs per algorithmic FLOP for the f16-pair form, 1/2.25 for Winograd.
+        peak = PEAK_TFLOPS[algo["mfma"] if algo else dtype]
+        per_alg = algo["executed_per_algorithmic"] if algo else 1.0
         if multi_stream:
             result["roofline_note"] = ("tile groups run on concurrent streams (overlapping event brackets): `achieved` = trunk "
                                        "FLOPs / wall time of the timed region, a lower bound")
         result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                               "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.workload),
-                              "algorithm": "winograd F(2x2,3x3), f32 MFMA 16x16x4" if wino else "direct implicit GEMM",
-                              "executed_frac": round(achieved / peak / (2.25 if wino else 1.0), 4),
-                              "kernel": "conv3x3_wino_f32_kernel / conv3x3_mfma_kernel / conv3x3_bf16_xl_kernel (the 345 dense-block convs per frame)",
+                              "algorithm": algo["algorithm"] if algo else "direct implicit GEMM, v_mfma_f32_32x32x16_bf16",
+                              "executed_frac": round(achieved * per_alg / peak, 4),
+                              "kernel": "conv3x3_f16x2_kernel / conv3x3_wino_f32_kernel / conv3x3_mfma_kernel / conv3x3_bf16_xl_kernel (the 345 dense-block convs per frame)",
                               "avg_launch_us": round(1e3 * k_ms / max(k_launches, 1), 2), "launches": int(k_launches)}
 
     if rank == 0:
@@ -237,7 +254,8 @@ def main():
             err = (ygpu - yref).abs().max().item()
             mse = ((ygpu - yref) ** 2).mean().item()
             result["parity_vs_cpu_oracle"] = {"max_abs": float(f"{err:.3e}"), "psnr_db": round(10 * np.log10(1.0 / max(mse, 1e-30)), 2),
-                                             "sample": base["sample"].split(",")[0], "tolerance": 1e-3 if dtype == "f32" else None}
+                                             "sample": base["sample"].split(",")[0], "tolerance": 1e-3 if dtype == "f32" else None,
+                                             "note": "oracle = torch CPU f32; an f64 evaluation of the same net differs from it by 1e-6"}
             result["gpu_over_cpu"] = round(value / world / base["value"], 1)
         print(json.dumps(result), flush=True)
     if world > 1:

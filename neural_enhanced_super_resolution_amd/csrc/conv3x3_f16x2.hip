@@ -46,12 +46,14 @@ constexpr int TW = 32, PW = TW + 2;
 #ifndef NESR_SPLIT_WAVES
 #define NESR_SPLIT_WAVES 4
 #endif
-constexpr int WAVES = NESR_SPLIT_WAVES;          // waves per workgroup
+constexpr int WAVES = NESR_SPLIT_WAVES;          // MFMA waves per workgroup
 constexpr int RW_S = 8 / WAVES, RW_L = 16 / WAVES;   // rows per wave of the 8x32 and the 16x32 tile
 
-template <int RW>
+// DMAW = extra waves that only issue the LDS-DMAs (0: the MFMA waves issue them themselves)
+template <int RW, int DMAW>
 struct Geo {
-    static constexpr int THREADS = 64 * WAVES;
+    static constexpr int LAUNCH_THREADS = 64 * (WAVES + DMAW);
+    static constexpr int THREADS = 64 * (DMAW ? DMAW : WAVES);   // lanes that share one DMA round
     static constexpr int TH = WAVES * RW;
     static constexpr int PH = TH + 2;
     static constexpr int NPIX = PH * PW;
@@ -127,10 +129,10 @@ __device__ unsigned long long g_stamps[256];
 #else
 #define STAMP(i) do { } while (0)
 #endif
-template <int RW, int ISLOTS>
-__global__ __launch_bounds__(64 * WAVES, (WAVES / 4) * (RW == RW_S ? 2 : 1)) void conv3x3_f16x2_kernel(ConvArgs a) {
+template <int RW, int ISLOTS, int DMAW>
+__global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (WAVES / 4) * (RW == RW_S ? 2 : 1)) void conv3x3_f16x2_kernel(ConvArgs a) {
     if (NESR_ABL & 1) return;
-    typedef Geo<RW> G;
+    typedef Geo<RW, DMAW> G;
     constexpr int THREADS = G::THREADS, TH = G::TH;
     constexpr int IN_ITEMS = G::IN_ITEMS, IN_ROUNDS = G::IN_ROUNDS, IN_BYTES = G::IN_BYTES;
     constexpr int W_ITEMS = W_ITEMS1;
@@ -139,11 +141,14 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES / 4) * (RW == RW_S ? 2 : 1)) voi
     constexpr int WRING = ISLOTS * IN_BYTES;   // LDS: [input ring][weight ring: 2 x W_BYTES]
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool is_dma = DMAW ? wave_all >= WAVES : true;     // issues the LDS-DMAs
+    const bool is_cmp = wave_all < WAVES;                    // runs the MFMAs and the epilogue
+    const int wave = is_cmp ? wave_all : wave_all - WAVES;   // index inside its role
+    const int tid = wave * 64 + lane;
 #if NESR_ABL & 64
-    const bool stamping = blockIdx.x == 77 && wave == 1;
+    const bool stamping = blockIdx.x == 77 && wave_all == 1;
 #endif
     STAMP(0);
 
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES / 4) * (RW == RW_S ? 2 : 1)) voi
     const unsigned lds_base = (unsigned)(size_t)(lds_char*)(smem);
     unsigned voff[IN_ROUNDS];
     unsigned okmask = 0;
-    {
+    if (is_dma) {
         int p = tid >> 2;
         int py = p / PW, px = p - py * PW;
         const int sl = tid & 3;
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES / 4) * (RW == RW_S ? 2 : 1)) voi
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) p_off[dx] = ((RW * wave) * PW + m + dx) * 64 + ((hh ^ (((m + dx) >> 2) & 3)) << 4);
     const int w_off = hh * 32 + m;   // item index inside a weight slab: ((tap*2 + plane)*2 + hh)*32 + cout
-    const bool active = (y0 + RW * wave) < a.h;
+    const bool active = is_cmp && (y0 + RW * wave) < a.h;
 
     // accumulators: [row][0] takes w_hi*x_hi, [row][1] the two cross terms (summed in the epilogue):
     // consecutive MFMAs never wait on each other's result, and the small terms add up among themselves
@@ -239,8 +244,10 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES / 4) * (RW == RW_S ? 2 : 1)) voi
 
     const int nchunks = a.cin / 16;
     STAMP(7);
+    if (is_dma) {
 #pragma unroll
-    for (int j = 0; j < NDMA; ++j) dma_round(0, 0, 0, j);
+        for (int j = 0; j < NDMA; ++j) dma_round(0, 0, 0, j);
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero padding is in LDS before the first barrier
     STAMP(1);
     if (NESR_ABL & 2) {
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES / 4) * (RW == RW_S ? 2 : 1)) voi
         STAMP(9 + 4 * c);
         // the next chunk's DMAs go out first (beside the MFMAs each costs 150+ cycles of issue instead of ~85:
         // measured, in-kernel stamps)
-        if (c + 1 < nchunks && !(NESR_ABL & 16)) {
+        if (is_dma && c + 1 < nchunks && !(NESR_ABL & 16)) {
 #pragma unroll
             for (int j = 0; j < NDMA; ++j) dma_round(c + 1, (c + 1) & 1, (c + 1) & 1, j);
         }
@@ -416,13 +423,13 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES / 4) * (RW == RW_S ? 2 : 1)) voi
 #endif
 }
 
-template <int RW, int ISLOTS>
+template <int RW, int ISLOTS, int DMAW>
 hipError_t launch_split(const ConvArgs& a, hipStream_t s) {
-    typedef Geo<RW> G;
+    typedef Geo<RW, DMAW> G;
     constexpr size_t shm = (size_t)ISLOTS * G::IN_BYTES + 2 * (size_t)(W_ITEMS1 * 16);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x2_kernel<RW, ISLOTS>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x2_kernel<RW, ISLOTS, DMAW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -430,7 +437,7 @@ hipError_t launch_split(const ConvArgs& a, hipStream_t s) {
     const long total = (long)((a.w_ + TW - 1) / TW) * ((a.h + G::TH - 1) / G::TH) * a.n * (a.coutp >> 5);
     if (total <= 0) return hipSuccess;
     if (total > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv3x3_f16x2_kernel<RW, ISLOTS>), dim3((unsigned)total), dim3(G::THREADS), shm, s, a);
+    hipLaunchKernelGGL((conv3x3_f16x2_kernel<RW, ISLOTS, DMAW>), dim3((unsigned)total), dim3(G::LAUNCH_THREADS), shm, s, a);
     return hipGetLastError();
 }
 
@@ -476,12 +483,24 @@ hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s) {
     if ((long long)a.in_h * a.in_w >= (1ll << 26)) return hipErrorInvalidValue;   // 32-bit byte offsets inside one image chunk
     if (a.in_map.pix != 32 || (a.out && (a.out_map.pix % 32 || a.out_coff % 16))) return hipErrorInvalidValue;
     if ((a.out_nchw || a.out_u8) && (a.coutp != 32 || a.cout_real < 1 || a.cout_real > 4)) return hipErrorInvalidValue;
-    // rows per wave: 1 (8x32-px tiles, two workgroups per CU) until 16x32-px tiles (2 rows per wave, one
-    // workgroup per CU: half the weight and halo traffic per pixel) fill the chip several times over
-    static const int force = [] { const char* e = getenv("NESR_SPLIT_ROWS"); return e ? atoi(e) : 0; }();
-    const long t2 = (long)((a.w_ + TW - 1) / TW) * ((a.h + 15) / 16) * a.n * (a.coutp >> 5);
-    const bool rw2 = force ? force == 2 : t2 >= 2048;
-    return rw2 ? launch_split<RW_L, 2>(a, s) : launch_split<RW_S, 2>(a, s);
+    // 8x32-px tiles, two workgroups per CU.  The 16x32-px form (one workgroup per CU, 30 % less DMA traffic
+    // per MFMA) stays behind NESR_SPLIT_TILE=16: with nothing else on the CU to run under its DMA issue and
+    // epilogue it measured 21 % slower (5 % slower as 8 waves, -DNESR_SPLIT_WAVES=8) on 12 tiles of 532x532.
+    static const int force = [] { const char* e = getenv("NESR_SPLIT_TILE"); return e ? atoi(e) : 0; }();   // 8 | 16 (rows)
+    if (force == 16) return launch_split<RW_L, 2, 0>(a, s);
+    // launches that give a CU at most one workgroup (a 512x512 frame's 32-channel layers): four extra waves
+    // issue the DMAs, so the MFMA waves never stall on LDS-DMA issue (~85 cycles each, 10 per chunk and wave;
+    // in-kernel stamps: -15 % per K-chunk).  With two workgroups per CU the other workgroup already fills
+    // those gaps and the extra waves only cost occupancy (measured +21 % on 6 tiles of 532x532).
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n;
+    }();
+    static const int dmaw = [] { const char* e = getenv("NESR_SPLIT_DMAW"); return e ? atoi(e) : -1; }();
+    const long t1 = (long)((a.w_ + TW - 1) / TW) * ((a.h + 7) / 8) * a.n * (a.coutp >> 5);
+    const bool producer = dmaw >= 0 ? dmaw > 0 : t1 <= cus;
+    return producer ? launch_split<RW_S, 2, 4>(a, s) : launch_split<RW_S, 2, 0>(a, s);
 }
 
 }  // namespace nesr

@@ -570,7 +570,9 @@ int nesr_preferred_batch(const nesr_ctx* c, int H, int W, int max_batch) {
     const bool xl = c->dtype == NESR_DTYPE_BF16 && (long)h * w > 256L * 256L;
     static const int geo = [] { const char* e = getenv("NESR_XL_GEOMETRY"); return e ? atoi(e) : 4; }();
     const int xl_th = geo == 8 ? 32 : 16;
-    const long per = xl ? (long)((h + xl_th - 1) / xl_th) * ((w + 31) / 32) : (long)((h + 7) / 8) * ((w + 15) / 16);
+    const bool sp = c->dtype == NESR_DTYPE_F32_SPLIT;   // 8x32-px tiles, two workgroups per CU
+    const long per = sp ? (long)((h + 7) / 8) * ((w + 31) / 32)
+                        : xl ? (long)((h + xl_th - 1) / xl_th) * ((w + 31) / 32) : (long)((h + 7) / 8) * ((w + 15) / 16);
     hipDeviceProp_t prop;
     int cus = 256;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;

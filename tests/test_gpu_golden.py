@@ -70,7 +70,9 @@ def test_wrapper_cases_vs_golden(cuda_device, golden_dir):
         lsb = 257 if q.dtype == np.uint16 else 1
         diff = np.abs(q.astype(np.int64) - want.astype(np.int64))
         assert diff.max() <= lsb, (name, diff.max())
-        assert (diff > 0).mean() < 1e-3, (name, (diff > 0).mean())       # ties only
+        # rounding flips only: an f32-level difference (~3e-6) moves a value across a rounding boundary of
+        # the 8-bit grid (step 3.9e-3) about once in a thousand, of the 16-bit grid (step 1.5e-5) more often
+        assert (diff > 0).mean() < (1e-2 if q.dtype == np.uint16 else 1e-3), (name, (diff > 0).mean())
         if f"{name}_f" in g.files:
             f, _, _ = up.enhance_float(img)
             assert np.abs(f - g[f"{name}_f"]).max() < TOL, name
@@ -149,12 +151,12 @@ def test_linearity_property_at_full_size(cuda_device):
     assert (lhs - rhs).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("algo,shift", [("f32-direct", 2), ("f32", 4)])
+@pytest.mark.parametrize("algo,shift", [("f32-direct", 2), ("f32", 2), ("f32-winograd", 4)])
 def test_translation_property_full_net(cuda_device, algo, shift):
-    """Away from borders the network commutes with translation: the direct kernel's per-pixel
-    arithmetic is position independent (any whole trunk pixel = 2 input px), the Winograd kernel's
-    depends only on the position inside its 2x2 output tile (2 trunk px = 4 input px).  A shift by that
-    period must reproduce the output bit for bit, shifted by 2x."""
+    """Away from borders the network commutes with translation: the direct and the f16-pair kernels'
+    per-pixel arithmetic is position independent (any whole trunk pixel = 2 input px), the Winograd
+    kernel's depends only on the position inside its 2x2 output tile (2 trunk px = 4 input px).  A shift
+    by that period must reproduce the output bit for bit, shifted by 2x."""
     sd = synthetic_state_dict(seed=3, num_in_ch=3, scale=2, num_block=1)
     net = RRDBNet(3, 3, scale=2, num_block=1, compute_dtype=algo)
     net.load_state_dict(sd)

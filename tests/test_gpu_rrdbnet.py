@@ -32,7 +32,7 @@ MODES = [
 
 @pytest.mark.parametrize("num_in_ch,scale", MODES)
 @pytest.mark.parametrize("hw", [(32, 48), (34, 46)])
-@pytest.mark.parametrize("algo", ["f32", "f32-direct"])
+@pytest.mark.parametrize("algo", ["f32", "f32-direct", "f32-winograd"])
 def test_mininet_matches_oracle(cuda_device, num_in_ch, scale, hw, algo):
     ours, ref = _pair(num_in_ch, scale, num_block=2, seed=3, compute_dtype=algo)
     x = torch.rand(1, num_in_ch, *hw, generator=torch.Generator().manual_seed(7))
@@ -44,7 +44,7 @@ def test_mininet_matches_oracle(cuda_device, num_in_ch, scale, hw, algo):
     assert err < 5e-5, f"fp32 path should be ~1e-6 off the oracle at 2 blocks, got {err}"
 
 
-@pytest.mark.parametrize("algo", ["f32", "f32-direct"])
+@pytest.mark.parametrize("algo", ["f32", "f32-direct", "f32-winograd"])
 def test_full_depth_x2plus_64(cuda_device, algo):
     ours, ref = _pair(3, 2, num_block=23, seed=0, compute_dtype=algo)
     x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(11))
