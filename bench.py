@@ -70,10 +70,11 @@ def host_threads(cap=16):
 
 
 def pmc_traffic(workload):
-    """HBM bytes per conv launch (average over the 351 launches of one frame) from the committed
-    rocprofv3 PMC passes profiles/r01/final_c2_pmc_fetch_write.txt: FETCH_SIZE x 2 (the gfx950
-    correction of MI355X_MICROARCH.md, HBM section) + WRITE_SIZE, two separate --pmc passes.  PMC
-    counters cannot be collected inside this process, so the figure comes from profiles/ (null if absent)."""
+    """HBM bytes per conv launch (average over the launches of one frame) from the committed rocprofv3 PMC
+    passes (profiles/r01/split_c2_pmc_fetch_write.txt; Winograd: final_c2_pmc_fetch_write.txt; collected
+    with tools/gpu_pmc_traffic.sh): FETCH_SIZE x 2 (the gfx950 correction of MI355X_MICROARCH.md, HBM
+    section) + WRITE_SIZE, two separate --pmc passes.  PMC counters cannot be collected inside this
+    process, so the figure comes from profiles/ (null if absent)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
@@ -140,8 +141,8 @@ def main():
     frame = synthetic_frame(wl["h"], wl["w"], seed=rank)            # uint8 HWC BGR, one per rank
     algo = None
     if dtype == "f32":
-        key = (args.f32_algo or os.environ.get("NESR_F32_ALGO") or "split").lower()
-        algo = F32_ALGOS[{"s": "split", "w": "winograd", "d": "direct"}[key[0]]]
+        key = {"s": "split", "w": "winograd", "d": "direct"}[(args.f32_algo or os.environ.get("NESR_F32_ALGO") or "split").lower()[0]]
+        algo = F32_ALGOS[key]
         os.environ.pop("NESR_F32_ALGO", None)   # the choice travels as compute_dtype
     net = RRDBNet(3, 3, scale=scale, compute_dtype=algo["compute_dtype"] if algo else dtype)
     up = RealESRGANer(scale=netscale, model_path={"params_ema": sd}, model=net, tile=wl["tile"], tile_pad=wl["tile_pad"],
@@ -228,7 +229,7 @@ def main():
             result["roofline_note"] = ("tile groups run on concurrent streams (overlapping event brackets): `achieved` = trunk "
                                        "FLOPs / wall time of the timed region, a lower bound")
         result["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                              "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.workload),
+                              "frac": round(achieved / peak, 4), "traffic": pmc_traffic(args.workload if (algo is None or algo is F32_ALGOS["split"]) else args.workload + "-" + key),
                               "algorithm": algo["algorithm"] if algo else "direct implicit GEMM, v_mfma_f32_32x32x16_bf16",
                               "executed_frac": round(achieved * per_alg / peak, 4),
                               "kernel": "conv3x3_f16x2_kernel / conv3x3_wino_f32_kernel / conv3x3_mfma_kernel / conv3x3_bf16_xl_kernel (the 345 dense-block convs per frame)",

@@ -129,7 +129,7 @@ __device__ unsigned long long g_stamps[256];
 #else
 #define STAMP(i) do { } while (0)
 #endif
-template <int RW, int ISLOTS, int DMAW>
+template <int RW, int ISLOTS, int DMAW, int NACC>
 __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (WAVES / 4) * (RW == RW_S ? 2 : 1)) void conv3x3_f16x2_kernel(ConvArgs a) {
     if (NESR_ABL & 1) return;
     typedef Geo<RW, DMAW> G;
@@ -179,29 +179,6 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
     const unsigned lds_base = (unsigned)(size_t)(lds_char*)(smem);
     unsigned voff[IN_ROUNDS];
     unsigned okmask = 0;
-    if (is_dma) {
-        int p = tid >> 2;
-        int py = p / PW, px = p - py * PW;
-        const int sl = tid & 3;
-#pragma unroll
-        for (int i = 0; i < IN_ROUNDS; ++i) {
-            const int k = tid + THREADS * i;
-            const int sg = sl ^ ((px >> 2) & 3);
-            const int Y = y0 - 1 + py, X = x0 - 1 + px;
-            const bool has = k < IN_ITEMS;
-            const bool ok = has && Y >= 0 && Y < a.h && X >= 0 && X < a.w_;
-            voff[i] = ((unsigned)(Y >> a.up) * (unsigned)a.in_w + (unsigned)(X >> a.up)) * 64u + sg * 16;
-            okmask |= ok ? (1u << i) : 0u;
-            if (has && !ok) {
-#pragma unroll
-                for (int sl2 = 0; sl2 < ISLOTS; ++sl2) *reinterpret_cast<f32x4*>(smem + sl2 * IN_BYTES + k * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            px += (THREADS / 4) % PW;
-            py += (THREADS / 4) / PW;
-            if (px >= PW) { px -= PW; py += 1; }
-        }
-    }
-    STAMP(6);
     const char* in_img = static_cast<const char*>(a.in) + (size_t)n * a.in_h * a.in_w * 64;
     const long long in_cstride = a.in_map.chunk * 2;   // bytes between K-chunks
     const char* wbase = static_cast<const char*>(a.w) + (size_t)cg * W_BYTES;
@@ -219,6 +196,34 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
             if ((okmask >> i) & 1u) glds16_s(in_img + (long long)c * in_cstride, voff[i], __builtin_amdgcn_readfirstlane(dst));
         }
     };
+    // the plan and chunk 0's DMAs together: the weight slab first (needs no plan), then every input round as
+    // soon as its offsets exist, so the first bytes are under way while the rest is still being computed
+    if (is_dma) {
+#pragma unroll
+        for (int j = 0; j < W_ROUNDS; ++j) dma_round(0, 0, 0, j);
+        int p = tid >> 2;
+        int py = p / PW, px = p - py * PW;
+        const int sl = tid & 3;
+#pragma unroll
+        for (int i = 0; i < IN_ROUNDS; ++i) {
+            const int k = tid + THREADS * i;
+            const int sg = sl ^ ((px >> 2) & 3);
+            const int Y = y0 - 1 + py, X = x0 - 1 + px;
+            const bool has = k < IN_ITEMS;
+            const bool ok = has && Y >= 0 && Y < a.h && X >= 0 && X < a.w_;
+            voff[i] = ((unsigned)(Y >> a.up) * (unsigned)a.in_w + (unsigned)(X >> a.up)) * 64u + sg * 16;
+            okmask |= ok ? (1u << i) : 0u;
+            dma_round(0, 0, 0, W_ROUNDS + i);
+            if (has && !ok) {
+#pragma unroll
+                for (int sl2 = 0; sl2 < ISLOTS; ++sl2) *reinterpret_cast<f32x4*>(smem + sl2 * IN_BYTES + k * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            px += (THREADS / 4) % PW;
+            py += (THREADS / 4) / PW;
+            if (px >= PW) { px -= PW; py += 1; }
+        }
+    }
+    STAMP(6);
 
     // ---- per-lane operand coordinates
     const int m = lane & 31, hh = lane >> 5;
@@ -230,13 +235,17 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
     const int w_off = hh * 32 + m;   // item index inside a weight slab: ((tap*2 + plane)*2 + hh)*32 + cout
     const bool active = is_cmp && (y0 + RW * wave) < a.h;
 
-    // accumulators: [row][0] takes w_hi*x_hi, [row][1] the two cross terms (summed in the epilogue):
-    // consecutive MFMAs never wait on each other's result, and the small terms add up among themselves
-    f32x16 acc[RW][2];
+    // accumulators.  NACC == 2: [row][0] takes w_hi*x_hi, [row][1] the two cross terms (summed in the
+    // epilogue): consecutive MFMAs never wait on each other's result, and the small terms add up among
+    // themselves.  NACC == 1 (4 rows per wave: the rows alone keep dependent MFMAs apart): one per row.
+    f32x16 acc[RW][NACC];
 #pragma unroll
     for (int r = 0; r < RW; ++r)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[r][0][e] = acc[r][1][e] = 0.f;
+        for (int q = 0; q < NACC; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][q][e] = 0.f;
+    constexpr int XA = NACC - 1;   // accumulator of the cross terms
     // bias now, so that its latency hides under the K loop
     f32x4 bs[4];
 #pragma unroll
@@ -244,10 +253,6 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
 
     const int nchunks = a.cin / 16;
     STAMP(7);
-    if (is_dma) {
-#pragma unroll
-        for (int j = 0; j < NDMA; ++j) dma_round(0, 0, 0, j);
-    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero padding is in LDS before the first barrier
     STAMP(1);
     if (NESR_ABL & 2) {
@@ -307,13 +312,13 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
                 }
 #pragma unroll
                 for (int r = 0; r < RW; ++r)
-                    acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][1]), acc[r][1], 0, 0, 0);
+                    acc[r][XA] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][1]), acc[r][XA], 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < RW; ++r)
                     acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][0]), acc[r][0], 0, 0, 0);
 #pragma unroll
                 for (int r = 0; r < RW; ++r)
-                    acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][0]), acc[r][1], 0, 0, 0);
+                    acc[r][XA] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][0]), acc[r][XA], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
 #pragma unroll
         for (int r = 0; r < RW; ++r)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sum += acc[r][0][e] + acc[r][1][e];
+            for (int e = 0; e < 16; ++e) sum += acc[r][0][e] + acc[r][XA][e];
         if (sum == 12345.678f) static_cast<float*>(a.out)[0] = sum;
         return;
     }
@@ -362,7 +367,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float x = (acc[r][0][4 * g + q] + acc[r][1][4 * g + q]) + bs[g][q];
+                float x = (NACC == 2 ? acc[r][0][4 * g + q] + acc[r][XA][4 * g + q] : acc[r][0][4 * g + q]) + bs[g][q];
                 if (a.lrelu) x = x > 0.f ? x : x * 0.2f;
                 if (res1) x = __fadd_rn(__fmul_rn(x, a.s1), r1[g][q]);
                 if (res2) x = __fadd_rn(__fmul_rn(x, a.s2), r2[g][q]);
@@ -423,13 +428,13 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
 #endif
 }
 
-template <int RW, int ISLOTS, int DMAW>
+template <int RW, int ISLOTS, int DMAW, int NACC>
 hipError_t launch_split(const ConvArgs& a, hipStream_t s) {
     typedef Geo<RW, DMAW> G;
     constexpr size_t shm = (size_t)ISLOTS * G::IN_BYTES + 2 * (size_t)(W_ITEMS1 * 16);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x2_kernel<RW, ISLOTS, DMAW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x2_kernel<RW, ISLOTS, DMAW, NACC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -437,7 +442,7 @@ hipError_t launch_split(const ConvArgs& a, hipStream_t s) {
     const long total = (long)((a.w_ + TW - 1) / TW) * ((a.h + G::TH - 1) / G::TH) * a.n * (a.coutp >> 5);
     if (total <= 0) return hipSuccess;
     if (total > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv3x3_f16x2_kernel<RW, ISLOTS, DMAW>), dim3((unsigned)total), dim3(G::LAUNCH_THREADS), shm, s, a);
+    hipLaunchKernelGGL((conv3x3_f16x2_kernel<RW, ISLOTS, DMAW, NACC>), dim3((unsigned)total), dim3(G::LAUNCH_THREADS), shm, s, a);
     return hipGetLastError();
 }
 
@@ -487,7 +492,8 @@ hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s) {
     // per MFMA) stays behind NESR_SPLIT_TILE=16: with nothing else on the CU to run under its DMA issue and
     // epilogue it measured 21 % slower (5 % slower as 8 waves, -DNESR_SPLIT_WAVES=8) on 12 tiles of 532x532.
     static const int force = [] { const char* e = getenv("NESR_SPLIT_TILE"); return e ? atoi(e) : 0; }();   // 8 | 16 (rows)
-    if (force == 16) return launch_split<RW_L, 2, 0>(a, s);
+    if (force == 16) return launch_split<RW_L, 2, 0, 2>(a, s);
+    if (force == 164) return launch_split<RW_L, 2, 4, 1>(a, s);   // 16x32 tiles + 4 DMA waves
     // launches that give a CU at most one workgroup (a 512x512 frame's 32-channel layers): four extra waves
     // issue the DMAs, so the MFMA waves never stall on LDS-DMA issue (~85 cycles each, 10 per chunk and wave;
     // in-kernel stamps: -15 % per K-chunk).  With two workgroups per CU the other workgroup already fills
@@ -500,7 +506,7 @@ hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s) {
     static const int dmaw = [] { const char* e = getenv("NESR_SPLIT_DMAW"); return e ? atoi(e) : -1; }();
     const long t1 = (long)((a.w_ + TW - 1) / TW) * ((a.h + 7) / 8) * a.n * (a.coutp >> 5);
     const bool producer = dmaw >= 0 ? dmaw > 0 : t1 <= cus;
-    return producer ? launch_split<RW_S, 2, 4>(a, s) : launch_split<RW_S, 2, 0>(a, s);
+    return producer ? launch_split<RW_S, 2, 4, 2>(a, s) : launch_split<RW_S, 2, 0, 2>(a, s);
 }
 
 }  // namespace nesr
