@@ -54,7 +54,7 @@ enum {
  *   unshuffle        : 0 = none (upstream scale=4), 2 = pixel_unshuffle(2) folded into the input
  *                      load (upstream scale=2), 4 = pixel_unshuffle(4) (upstream scale=1).
  *                      forward() then expects C = conv_first_in_ch / unshuffle^2 input channels.
- *   dtype            : arithmetic type of activations/weights (accumulation is always f32).
+ *   dtype            : one of NESR_DTYPE_* -- storage and arithmetic of activations/weights (accumulation is always f32).
  */
 int nesr_create(nesr_ctx** out, int device_id, int conv_first_in_ch, int unshuffle, int num_feat,
                 int num_block, int num_grow_ch, int num_out_ch, int dtype);
