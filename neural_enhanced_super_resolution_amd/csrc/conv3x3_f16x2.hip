@@ -125,17 +125,34 @@ __device__ __forceinline__ f32x4 ld4_split(const uint16_t* p) {
 #endif
 #if NESR_ABL & 64
 __device__ unsigned long long g_stamps[256];
-#define STAMP(i) do { if (stamping) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0 && (i) < 256) g_stamps[(i)] = t_; } } while (0)
+#define STAMP(i) do { if (stamping) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0 && (i) < 200) g_stamps[(i)] = t_; \
+    if ((i) == 0 || (i) == 4) { unsigned long long r_ = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (lane == 0) g_stamps[200 + (i)] = r_; } } } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #endif
-template <int RW, int ISLOTS, int DMAW, int NACC>
+// timing experiment (-DNESR_ABL=128, values WRONG): each 32x32x16 MFMA replaced by two 16x16x32 MFMAs of the same
+// total FLOPs on two quarters of the accumulator -- does the chip hold a higher clock on that shape?
+__device__ __forceinline__ f32x16 MFMA32(f16x8 a, f16x8 b, f32x16 c, int, int, int) {
+#if NESR_ABL & 128
+    f32x4 lo = __builtin_shufflevector(c, c, 0, 1, 2, 3), hi = __builtin_shufflevector(c, c, 8, 9, 10, 11);
+    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, lo, 0, 0, 0);
+    hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, hi, 0, 0, 0);
+    c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3];
+    c[8] = hi[0]; c[9] = hi[1]; c[10] = hi[2]; c[11] = hi[3];
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// NT = 32-channel output groups per workgroup (2: a 64-channel layer stages its input once)
+template <int RW, int ISLOTS, int DMAW, int NACC, int NT>
 __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (WAVES / 4) * (RW == RW_S ? 2 : 1)) void conv3x3_f16x2_kernel(ConvArgs a) {
     if (NESR_ABL & 1) return;
     typedef Geo<RW, DMAW> G;
     constexpr int THREADS = G::THREADS, TH = G::TH;
     constexpr int IN_ITEMS = G::IN_ITEMS, IN_ROUNDS = G::IN_ROUNDS, IN_BYTES = G::IN_BYTES;
-    constexpr int W_ITEMS = W_ITEMS1;
+    constexpr int W_ITEMS = W_ITEMS1 * NT;   // the NT slabs of a chunk are consecutive in the packed weights
     constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
     constexpr int W_BYTES = W_ITEMS * 16;
     constexpr int WRING = ISLOTS * IN_BYTES;   // LDS: [input ring][weight ring: 2 x W_BYTES]
@@ -154,7 +171,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
 
     static_assert(ISLOTS == 2, "two-slot rings: every wait is vmcnt(0)");
     // ---- XCD-aware work index (bijective for any count); the cout groups of one tile are neighbours
-    const int CG = a.coutp >> 5;
+    const int CG = a.coutp / (32 * NT);
     const int tiles_x = (a.w_ + TW - 1) / TW;
     const int tiles_y = (a.h + TH - 1) / TH;
     const int total = tiles_x * tiles_y * a.n * CG;
@@ -238,18 +255,22 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
     // accumulators.  NACC == 2: [row][0] takes w_hi*x_hi, [row][1] the two cross terms (summed in the
     // epilogue): consecutive MFMAs never wait on each other's result, and the small terms add up among
     // themselves.  NACC == 1 (4 rows per wave: the rows alone keep dependent MFMAs apart): one per row.
-    f32x16 acc[RW][NACC];
+    f32x16 acc[RW][NT][NACC];
 #pragma unroll
     for (int r = 0; r < RW; ++r)
 #pragma unroll
-        for (int q = 0; q < NACC; ++q)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[r][q][e] = 0.f;
+            for (int q = 0; q < NACC; ++q)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[r][t][q][e] = 0.f;
     constexpr int XA = NACC - 1;   // accumulator of the cross terms
     // bias now, so that its latency hides under the K loop
-    f32x4 bs[4];
+    f32x4 bs[NT][4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) bs[g] = *reinterpret_cast<const f32x4*>(a.bias + 32 * cg + 8 * g + 4 * hh);
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bs[t][g] = *reinterpret_cast<const f32x4*>(a.bias + 32 * (cg * NT + t) + 8 * g + 4 * hh);
 
     const int nchunks = a.cin / 16;
     STAMP(7);
@@ -281,11 +302,14 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
                 return *reinterpret_cast<const f32x4*>(st + (p_off[dx] ^ (plane << 5)) + r * (PW * 64));
             };
             f32x4 P[2][RW + 2][2];
-            f32x4 Wf[2][2];
+            f32x4 Wf[2][NT][2];   // [buffer][cout group][hi | lo]; slab t starts W_ITEMS1 items after slab t-1
 #pragma unroll
             for (int r = 0; r < RW + 2; ++r) { P[0][r][0] = pix_frag(r, 0, 0); P[0][r][1] = pix_frag(r, 0, 1); }
-            Wf[0][0] = sw[w_off];
-            Wf[0][1] = sw[w_off + 64];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                Wf[0][t][0] = sw[w_off + t * W_ITEMS1];
+                Wf[0][t][1] = sw[w_off + t * W_ITEMS1 + 64];
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 9; ++s) {
@@ -293,8 +317,11 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
                 if (s + 1 < 9) {
                     const int dx1 = (s + 1) / 3, dy1 = (s + 1) - dx1 * 3;
                     const int tap1 = dy1 * 3 + dx1;
-                    Wf[(s + 1) & 1][0] = sw[w_off + tap1 * 128];
-                    Wf[(s + 1) & 1][1] = sw[w_off + tap1 * 128 + 64];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        Wf[(s + 1) & 1][t][0] = sw[w_off + t * W_ITEMS1 + tap1 * 128];
+                        Wf[(s + 1) & 1][t][1] = sw[w_off + t * W_ITEMS1 + tap1 * 128 + 64];
+                    }
                 }
                 if (dy == 0 && dx < 2) {
 #pragma unroll
@@ -304,21 +331,24 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const f16x8 wh = __builtin_bit_cast(f16x8, Wf[s & 1][0]), wl = __builtin_bit_cast(f16x8, Wf[s & 1][1]);
                 if (NESR_ABL & 8) {
 #pragma unroll
-                    for (int r = 0; r < RW; ++r) acc[r][0][0] += Wf[s & 1][0][0] + Wf[s & 1][1][0] + P[dx & 1][r + dy][0][0] + P[dx & 1][r + dy][1][0];
+                    for (int r = 0; r < RW; ++r) acc[r][0][0][0] += Wf[s & 1][0][0][0] + Wf[s & 1][NT - 1][1][0] + P[dx & 1][r + dy][0][0] + P[dx & 1][r + dy][1][0];
                     continue;
                 }
 #pragma unroll
-                for (int r = 0; r < RW; ++r)
-                    acc[r][XA] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][1]), acc[r][XA], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) {
+                    const f16x8 wh = __builtin_bit_cast(f16x8, Wf[s & 1][t][0]), wl = __builtin_bit_cast(f16x8, Wf[s & 1][t][1]);
 #pragma unroll
-                for (int r = 0; r < RW; ++r)
-                    acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][0]), acc[r][0], 0, 0, 0);
+                    for (int r = 0; r < RW; ++r)
+                        acc[r][t][XA] = MFMA32(wh, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][1]), acc[r][t][XA], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < RW; ++r)
-                    acc[r][XA] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][0]), acc[r][XA], 0, 0, 0);
+                    for (int r = 0; r < RW; ++r)
+                        acc[r][t][0] = MFMA32(wh, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][0]), acc[r][t][0], 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < RW; ++r)
+                        acc[r][t][XA] = MFMA32(wl, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][0]), acc[r][t][XA], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -331,7 +361,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
 #pragma unroll
         for (int r = 0; r < RW; ++r)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sum += acc[r][0][e] + acc[r][XA][e];
+            for (int e = 0; e < 16; ++e) sum += acc[r][0][0][e] + acc[r][NT - 1][XA][e];
         if (sum == 12345.678f) static_cast<float*>(a.out)[0] = sum;
         return;
     }
@@ -341,13 +371,15 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
     const int X = x0 + m;
     const bool xok = X < a.w_;
     const int Xc = xok ? X : 0;
-    const int cbase = 32 * cg;
     const uint16_t* res1 = static_cast<const uint16_t*>(a.res1);
     const uint16_t* res2 = static_cast<const uint16_t*>(a.res2);
     uint16_t* out = static_cast<uint16_t*>(a.out);
     uint16_t* out2 = static_cast<uint16_t*>(a.out2);
 #pragma unroll
-    for (int r = 0; r < RW; ++r) {
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int cbase = 32 * (cg * NT + t);
         const int Y = y0 + RW * wave + r;
         const bool valid = xok && Y < a.h;
         const size_t pix = ((size_t)n * a.h + (Y < a.h ? Y : 0)) * a.w_ + Xc;
@@ -367,7 +399,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
         for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float x = (NACC == 2 ? acc[r][0][4 * g + q] + acc[r][XA][4 * g + q] : acc[r][0][4 * g + q]) + bs[g][q];
+                float x = (NACC == 2 ? acc[r][t][0][4 * g + q] + acc[r][t][XA][4 * g + q] : acc[r][t][0][4 * g + q]) + bs[t][g][q];
                 if (a.lrelu) x = x > 0.f ? x : x * 0.2f;
                 if (res1) x = __fadd_rn(__fmul_rn(x, a.s1), r1[g][q]);
                 if (res2) x = __fadd_rn(__fmul_rn(x, a.s2), r2[g][q]);
@@ -405,7 +437,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
                     store16(p + 16, wlo[j]);
                 }
             }
-            if (a.cout_real > 0 && hh == 0 && cg == 0) {
+            if (a.cout_real > 0 && hh == 0 && cbase == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (q >= a.cout_real) break;
@@ -428,21 +460,21 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
 #endif
 }
 
-template <int RW, int ISLOTS, int DMAW, int NACC>
+template <int RW, int ISLOTS, int DMAW, int NACC, int NT>
 hipError_t launch_split(const ConvArgs& a, hipStream_t s) {
     typedef Geo<RW, DMAW> G;
-    constexpr size_t shm = (size_t)ISLOTS * G::IN_BYTES + 2 * (size_t)(W_ITEMS1 * 16);
+    constexpr size_t shm = (size_t)ISLOTS * G::IN_BYTES + 2 * (size_t)(W_ITEMS1 * NT * 16);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x2_kernel<RW, ISLOTS, DMAW, NACC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x2_kernel<RW, ISLOTS, DMAW, NACC, NT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const long total = (long)((a.w_ + TW - 1) / TW) * ((a.h + G::TH - 1) / G::TH) * a.n * (a.coutp >> 5);
+    const long total = (long)((a.w_ + TW - 1) / TW) * ((a.h + G::TH - 1) / G::TH) * a.n * (a.coutp / (32 * NT));
     if (total <= 0) return hipSuccess;
     if (total > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv3x3_f16x2_kernel<RW, ISLOTS, DMAW, NACC>), dim3((unsigned)total), dim3(G::LAUNCH_THREADS), shm, s, a);
+    hipLaunchKernelGGL((conv3x3_f16x2_kernel<RW, ISLOTS, DMAW, NACC, NT>), dim3((unsigned)total), dim3(G::LAUNCH_THREADS), shm, s, a);
     return hipGetLastError();
 }
 
@@ -492,8 +524,10 @@ hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s) {
     // per MFMA) stays behind NESR_SPLIT_TILE=16: with nothing else on the CU to run under its DMA issue and
     // epilogue it measured 21 % slower (5 % slower as 8 waves, -DNESR_SPLIT_WAVES=8) on 12 tiles of 532x532.
     static const int force = [] { const char* e = getenv("NESR_SPLIT_TILE"); return e ? atoi(e) : 0; }();   // 8 | 16 (rows)
-    if (force == 16) return launch_split<RW_L, 2, 0, 2>(a, s);
-    if (force == 164) return launch_split<RW_L, 2, 4, 1>(a, s);   // 16x32 tiles + 4 DMA waves
+    if (force == 16) return launch_split<RW_L, 2, 0, 2, 1>(a, s);
+    if (force == 164) return launch_split<RW_L, 2, 4, 1, 1>(a, s);   // 16x32 tiles + 4 DMA waves
+    static const int nt2 = [] { const char* e = getenv("NESR_SPLIT_NT2"); return e ? atoi(e) : 0; }();
+    if (nt2 && a.coutp == 64) return launch_split<RW_S, 2, 4, 1, 2>(a, s);   // 64 couts per workgroup + 4 DMA waves
     // launches that give a CU at most one workgroup (a 512x512 frame's 32-channel layers): four extra waves
     // issue the DMAs, so the MFMA waves never stall on LDS-DMA issue (~85 cycles each, 10 per chunk and wave;
     // in-kernel stamps: -15 % per K-chunk).  With two workgroups per CU the other workgroup already fills
@@ -506,7 +540,8 @@ hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s) {
     static const int dmaw = [] { const char* e = getenv("NESR_SPLIT_DMAW"); return e ? atoi(e) : -1; }();
     const long t1 = (long)((a.w_ + TW - 1) / TW) * ((a.h + 7) / 8) * a.n * (a.coutp >> 5);
     const bool producer = dmaw >= 0 ? dmaw > 0 : t1 <= cus;
-    return producer ? launch_split<RW_S, 2, 4, 2>(a, s) : launch_split<RW_S, 2, 0, 2>(a, s);
+    constexpr int NA = WAVES == 8 ? 1 : 2;   // the 8-wave build has 128 registers per wave
+    return producer ? launch_split<RW_S, 2, 4, NA, 1>(a, s) : launch_split<RW_S, 2, 0, NA, 1>(a, s);
 }
 
 }  // namespace nesr

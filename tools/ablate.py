@@ -40,6 +40,9 @@ for sh in a.shapes.split(","):
         nch = -(-cin // 16)
         print("  stamps (cycles from kernel start): prologue issued %d, loop end %d, epilogue issued %d, stores done %d" %
               (buf[1] - t0, buf[2] - t0, buf[3] - t0, buf[4] - t0))
+        if buf[204] > buf[200]:
+            print("  in-kernel clock %.2f GHz (s_memtime / s_memrealtime at 100 MHz), workgroup lifetime %.2f us" %
+                  ((buf[4] - buf[0]) / (buf[204] - buf[200]) * 0.1, (buf[204] - buf[200]) / 100.0))
         print("  setup: index %d, dma plan %d, operands/bias %d, prologue dma issue %d" % (buf[5] - t0, buf[6] - buf[5], buf[7] - buf[6], buf[1] - buf[7]))
         for c in range(nch):
             b = [buf[8 + 4 * c + i] for i in range(4)]
