@@ -46,6 +46,9 @@ constexpr int TW = 32, PW = TW + 2;
 #ifndef NESR_SPLIT_WAVES
 #define NESR_SPLIT_WAVES 4
 #endif
+#ifndef NESR_SPLIT_SHAPE
+#define NESR_SPLIT_SHAPE 16   // MFMA shape: 16 = v_mfma_f32_16x16x32_f16 (K = two (tap, product) units), 32 = 32x32x16
+#endif
 constexpr int WAVES = NESR_SPLIT_WAVES;          // MFMA waves per workgroup
 constexpr int RW_S = 8 / WAVES, RW_L = 16 / WAVES;   // rows per wave of the 8x32 and the 16x32 tile
 
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
     STAMP(0);
 
     static_assert(ISLOTS == 2, "two-slot rings: every wait is vmcnt(0)");
+    constexpr bool S16 = NESR_SPLIT_SHAPE == 16 && NT == 1;
     // ---- XCD-aware work index (bijective for any count); the cout groups of one tile are neighbours
     const int CG = a.coutp / (32 * NT);
     const int tiles_x = (a.w_ + TW - 1) / TW;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
 #pragma unroll
         for (int i = 0; i < IN_ROUNDS; ++i) {
             const int k = tid + THREADS * i;
-            const int sg = sl ^ ((px >> 2) & 3);
+            const int sg = S16 ? sl ^ (((px >> 2) & 1) << 1) : sl ^ ((px >> 2) & 3);
             const int Y = y0 - 1 + py, X = x0 - 1 + px;
             const bool has = k < IN_ITEMS;
             const bool ok = has && Y >= 0 && Y < a.h && X >= 0 && X < a.w_;
@@ -251,6 +255,39 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
     for (int dx = 0; dx < 3; ++dx) p_off[dx] = ((RW * wave) * PW + m + dx) * 64 + ((hh ^ (((m + dx) >> 2) & 3)) << 4);
     const int w_off = hh * 32 + m;   // item index inside a weight slab: ((tap*2 + plane)*2 + hh)*32 + cout
     const bool active = is_cmp && (y0 + RW * wave) < a.h;
+
+    // ---- 16x16x32 form.  The MFMA's K = 32 is two units of 16 channels: lanes 0-31 (k-groups g = 0,1 = channel
+    // halves) feed unit 0, lanes 32-63 unit 1, and a unit is one (tap, plane) choice -- just another per-lane LDS
+    // address.  Steps 0-2 pair the taps (dy 0 | dy 1) of column dx = step, step 3 pairs (2,0) | (2,1); with
+    // WH/WL = [w(tap a) | w(tap b)] and XH/XL = [x(tap a) | x(tap b)] a step is WH*XH + WH*XL + WL*XH.  Step 4 is
+    // tap (2,2) alone: [w_hi | w_hi] * [x_hi | x_lo] and [w_lo | 0] * [x_hi | x_hi].  14 MFMAs per 16x16 tile and
+    // chunk instead of 13.5; the chip holds a ~20 % higher clock on this shape (tools/probes/mfma_shape.hip).
+    // Tiles of a wave: rows r, pixel halves nh (16 px), cout halves mt (16 couts).  LDS slot swizzle for this lane
+    // order: physical slot = slot ^ (bit 2 of the padded column << 1) (conflict-free for the b128 lane groups).
+    const int j16 = lane & 15, g4 = lane >> 4, un = g4 >> 1, kh = g4 & 1;
+    int b16[5][2], a16[5], b16x[2];
+#pragma unroll
+    for (int st_ = 0; st_ < 5; ++st_) {
+        const int dy = st_ < 3 ? un : 2;
+        const int dx = st_ < 3 ? st_ : (st_ == 3 ? un : 2);
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+            const int col = 16 * nh + j16 + dx;
+            b16[st_][nh] = ((RW * wave + dy) * PW + col) * 64 + ((kh ^ (((col >> 2) & 1) << 1)) << 4);
+        }
+        a16[st_] = ((((dy * 3 + dx) * 2) * 2 + kh) * 32 + j16) * 16;
+    }
+    b16x[0] = b16[4][0] ^ (un << 5);   // [x_hi | x_lo] of the last tap
+    b16x[1] = b16[4][1] ^ (un << 5);
+    f32x4 acc16[RW][2][2][NACC];       // [row][pixel half][cout half][main | cross]
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int q = 0; q < NACC; ++q) acc16[r][nh][mt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // accumulators.  NACC == 2: [row][0] takes w_hi*x_hi, [row][1] the two cross terms (summed in the
     // epilogue): consecutive MFMAs never wait on each other's result, and the small terms add up among
@@ -295,7 +332,70 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
             for (int j = 0; j < NDMA; ++j) dma_round(c + 1, (c + 1) & 1, (c + 1) & 1, j);
         }
         STAMP(10 + 4 * c);
-        if (active) {
+        if (active && S16) {
+            const char* st = smem + (c & 1) * IN_BYTES;
+            const char* swb = smem + WRING + (c & 1) * W_BYTES;
+            f32x4 Af[2][2][2];        // [buffer][cout half][variant]
+            f32x4 Bf[2][RW][2][2];    // [buffer][row][pixel half][variant]
+            auto load_step = [&](int s_, int buf) {   // s_ is a compile-time constant at every call site
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    Af[buf][mt][0] = *reinterpret_cast<const f32x4*>(swb + a16[s_] + mt * 256);
+                    f32x4 lo = *reinterpret_cast<const f32x4*>(swb + a16[s_] + mt * 256 + 1024);
+                    if (s_ == 4 && un) lo = f32x4{0.f, 0.f, 0.f, 0.f};    // [w_lo | 0]
+                    Af[buf][mt][1] = lo;
+                }
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh) {
+                        const int o0 = s_ == 4 ? b16x[nh] : b16[s_][nh];            // XH, or [x_hi | x_lo]
+                        const int o1 = s_ == 4 ? b16[4][nh] : (b16[s_][nh] ^ 32);   // XL, or [x_hi | x_hi]
+                        Bf[buf][r][nh][0] = *reinterpret_cast<const f32x4*>(st + o0 + r * (PW * 64));
+                        Bf[buf][r][nh][1] = *reinterpret_cast<const f32x4*>(st + o1 + r * (PW * 64));
+                    }
+            };
+            load_step(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s_ = 0; s_ < 5; ++s_) {
+                const int buf = s_ & 1;
+                if (s_ + 1 < 5) load_step(s_ + 1, buf ^ 1);
+                if (NESR_ABL & 8) {
+                    acc16[0][0][0][0][0] += Af[buf][0][0][0] + Af[buf][1][1][0] + Bf[buf][0][0][0][0] + Bf[buf][RW - 1][1][1][0];
+                    continue;
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const f16x8 a0 = __builtin_bit_cast(f16x8, Af[buf][mt][0]), a1 = __builtin_bit_cast(f16x8, Af[buf][mt][1]);
+#pragma unroll
+                    for (int r = 0; r < RW; ++r)
+#pragma unroll
+                        for (int nh = 0; nh < 2; ++nh) {
+                            const f16x8 x0_ = __builtin_bit_cast(f16x8, Bf[buf][r][nh][0]), x1_ = __builtin_bit_cast(f16x8, Bf[buf][r][nh][1]);
+                            if (s_ < 4) {
+                                acc16[r][nh][mt][XA] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x1_, acc16[r][nh][mt][XA], 0, 0, 0);
+                                acc16[r][nh][mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x0_, acc16[r][nh][mt][0], 0, 0, 0);
+                                acc16[r][nh][mt][XA] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x0_, acc16[r][nh][mt][XA], 0, 0, 0);
+                            } else {
+                                acc16[r][nh][mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x0_, acc16[r][nh][mt][0], 0, 0, 0);
+                                acc16[r][nh][mt][XA] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1_, acc16[r][nh][mt][XA], 0, 0, 0);
+                            }
+                        }
+                }
+                // the next step's 4 + 4 RW fragment reads ride between this step's MFMAs (two MFMAs, one read)
+                // instead of in front of them
+                if (s_ + 1 < 5) {
+#pragma unroll
+                    for (int i = 0; i < 4 + 4 * RW; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (active && !S16) {
             const char* st = smem + (c & 1) * IN_BYTES;
             const f32x4* sw = reinterpret_cast<const f32x4*>(smem + WRING + (c & 1) * W_BYTES);
             auto pix_frag = [&](int r, int dx, int plane) -> f32x4 {
@@ -361,11 +461,88 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (W
 #pragma unroll
         for (int r = 0; r < RW; ++r)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sum += acc[r][0][0][e] + acc[r][NT - 1][XA][e];
+            for (int e = 0; e < 16; ++e) sum += acc[r][0][0][e] + acc[r][NT - 1][XA][e] + acc16[r][e & 1][(e >> 1) & 1][(e >> 2) & (NACC - 1)][e & 3];
         if (sum == 12345.678f) static_cast<float*>(a.out)[0] = sum;
         return;
     }
 
+    if constexpr (S16) {
+        // ---- epilogue of the 16x16x32 form.  C/D layout: lane (pixel j16, k-group g4) holds couts 16 mt + 4 g4 + i.
+        // v_permlane16_swap of the mt = 0 / mt = 1 values leaves every lane with 8 consecutive couts of its
+        // pixel: base 0 / 16 / 8 / 24 for g4 = 0 / 1 / 2 / 3 (tools/probes/mfma16_layout.hip).
+        const int cb = 32 * cg + (g4 & 1) * 16 + (g4 >> 1) * 8;
+        const uint16_t* res1 = static_cast<const uint16_t*>(a.res1);
+        const uint16_t* res2 = static_cast<const uint16_t*>(a.res2);
+        uint16_t* out = static_cast<uint16_t*>(a.out);
+        uint16_t* out2 = static_cast<uint16_t*>(a.out2);
+        const f32x4 bz0 = *reinterpret_cast<const f32x4*>(a.bias + cb), bz1 = *reinterpret_cast<const f32x4*>(a.bias + cb + 4);
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+                const int Y = y0 + RW * wave + r, X = x0 + 16 * nh + j16;
+                const bool valid = X < a.w_ && Y < a.h;
+                const size_t pix = ((size_t)n * a.h + (Y < a.h ? Y : 0)) * a.w_ + (X < a.w_ ? X : 0);
+                auto at = [&](const Map& mp, int c) -> size_t { return (size_t)(c >> 4) * mp.chunk + pix * mp.pix + (c & 15); };
+                f32x4 v0, v1;   // couts cb .. cb+3, cb+4 .. cb+7
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float e = NACC == 2 ? acc16[r][nh][0][0][i] + acc16[r][nh][0][XA][i] : acc16[r][nh][0][0][i];
+                    const float o = NACC == 2 ? acc16[r][nh][1][0][i] + acc16[r][nh][1][XA][i] : acc16[r][nh][1][0][i];
+                    const auto sw_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(e), __float_as_uint(o), false, false);
+                    v0[i] = __uint_as_float(sw_[0]);
+                    v1[i] = __uint_as_float(sw_[1]);
+                }
+                v0 += bz0;
+                v1 += bz1;
+                if (a.lrelu) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v0[i] = v0[i] > 0.f ? v0[i] : v0[i] * 0.2f; v1[i] = v1[i] > 0.f ? v1[i] : v1[i] * 0.2f; }
+                }
+                if (res1) {
+                    const f32x4 q0 = ld4_split(res1 + at(a.res1_map, cb)), q1 = ld4_split(res1 + at(a.res1_map, cb + 4));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s1), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s1), q1[i]); }
+                }
+                if (res2) {
+                    const f32x4 q0 = ld4_split(res2 + at(a.res2_map, cb)), q1 = ld4_split(res2 + at(a.res2_map, cb + 4));
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s2), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s2), q1[i]); }
+                }
+                uint2 h0, l0, h1, l1;
+                split4(v0, h0, l0);
+                split4(v1, h1, l1);
+                const uint4 whi = uint4{h0.x, h0.y, h1.x, h1.y}, wlo = uint4{l0.x, l0.y, l1.x, l1.y};
+                if (valid) {
+                    if (out) {
+                        uint16_t* p = out + at(a.out_map, a.out_coff + cb);
+                        store16(p, whi);
+                        store16(p + 16, wlo);
+                    }
+                    if (out2) {
+                        uint16_t* p = out2 + at(a.out2_map, cb);
+                        store16(p, whi);
+                        store16(p + 16, wlo);
+                    }
+                    if (a.cout_real > 0 && cb == 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (q >= a.cout_real) break;
+                            const float x = v0[q];
+                            if (a.out_nchw) a.out_nchw[(((size_t)n * a.cout_real + q) * a.h + Y) * a.w_ + X] = x;
+                            if (a.out_u8) {
+                                float qv = fminf(fmaxf(x, 0.f), 1.f) * 255.0f;
+                                qv = a.u8_round ? rintf(qv) : truncf(qv);
+                                const int ch = a.u8_flip ? (a.cout_real - 1 - q) : q;
+                                a.out_u8[pix * a.cout_real + ch] = (uint8_t)qv;
+                            }
+                        }
+                    }
+                }
+            }
+        STAMP(3);
+        return;
+    }
     // ---- epilogue: lane = pixel column m of rows RW*wave + r; regs = 4-channel runs 8g + 4hh of this
     // workgroup's 32 output channels (network channels 32 cg + ...)
     const int X = x0 + m;
