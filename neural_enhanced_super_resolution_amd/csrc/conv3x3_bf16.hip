@@ -26,7 +26,7 @@
 //               are immediate offsets.
 //   operands  : for one horizontal tap dx the wave reads 6 pixel fragments (rows -1..4) once and
 //               uses each for up to 3 vertical taps: 6 + 3*NT ds_read_b128 per 12*NT MFMAs; the next
-//               step's fragments are read during the current step's MFMAs (sched_barrier-pinned).
+//               step's fragments are read between the current step's MFMAs (sched_group_barrier).
 //   placement : blockIdx -> tile through the bijective XCD remap (neighbouring tiles share an L2).
 //   epilogue  : weights are the MFMA A operand, pixels the B operand -> a lane owns runs of 4
 //               consecutive channels of one pixel; pairs of runs are exchanged between the two
@@ -252,7 +252,6 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_bf16_xl_kernel(ConvArgs
 #pragma unroll
                     for (int r = 0; r < 6; ++r) P[(dx + 1) & 1][r] = pix_frag(r, dx + 1);
                 }
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -260,6 +259,17 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_bf16_xl_kernel(ConvArgs
                         acc[r][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, Wf[s & 1][t]),
                                                                             __builtin_bit_cast(bf16x8, P[dx & 1][r + dy]),
                                                                             acc[r][t], 0, 0, 0);
+                // the next step's fragment reads ride between this step's MFMAs instead of in front of them
+                // (in-process A/B: -1.6 % / -1.9 % forward time on 24 / 6 tiles of 532x532)
+                {
+                    constexpr int NRD = NT;           // weight fragments of the next tap
+#pragma unroll
+                    for (int i = 0; i < 4 * NT; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (dy == 0 && dx < 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        else if (i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
