@@ -150,7 +150,7 @@ __device__ __forceinline__ f32x16 MFMA32(f16x8 a, f16x8 b, f32x16 c, int, int, i
 
 // NT = 32-channel output groups per workgroup (2: a 64-channel layer stages its input once)
 template <int RW, int ISLOTS, int DMAW, int NACC, int NT>
-__global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : (WAVES / 4) * (RW == RW_S ? 2 : 1)) void conv3x3_f16x2_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES + DMAW) / 4 : (WAVES / 4) * (RW == RW_S ? 2 : 1)) void conv3x3_f16x2_kernel(ConvArgs a) {
     if (NESR_ABL & 1) return;
     typedef Geo<RW, DMAW> G;
     constexpr int THREADS = G::THREADS, TH = G::TH;
@@ -718,6 +718,8 @@ hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s) {
     const long t1 = (long)((a.w_ + TW - 1) / TW) * ((a.h + 7) / 8) * a.n * (a.coutp >> 5);
     const bool producer = dmaw >= 0 ? dmaw > 0 : t1 <= cus;
     constexpr int NA = WAVES == 8 ? 1 : 2;   // the 8-wave build has 128 registers per wave
+    static const int d2 = [] { const char* e = getenv("NESR_SPLIT_D2"); return e ? atoi(e) : 0; }();
+    if (d2 && !producer) return launch_split<RW_S, 2, 2, 1, 1>(a, s);   // two workgroups per CU, each 4 MFMA + 2 DMA waves (<= 168 registers)
     return producer ? launch_split<RW_S, 2, 4, NA, 1>(a, s) : launch_split<RW_S, 2, 0, NA, 1>(a, s);
 }
 
