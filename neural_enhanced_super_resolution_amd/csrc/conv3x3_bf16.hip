@@ -375,12 +375,10 @@ template <int NT, int WAVES, int ISLOTS>
 hipError_t launch_xl(const ConvArgs& a, hipStream_t s) {
     typedef Geo<WAVES> G;
     constexpr size_t shm = (size_t)ISLOTS * G::IN_BYTES + 2 * (size_t)(9 * 2 * 32 * NT * 16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_xl_kernel<NT, WAVES, ISLOTS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    static unsigned long long attr_done = 0;
+    {
+        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_bf16_xl_kernel<NT, WAVES, ISLOTS>), shm, attr_done);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const int tiles = ((a.w_ + TW - 1) / TW) * ((a.h + G::TH - 1) / G::TH) * a.n;
     hipLaunchKernelGGL((conv3x3_bf16_xl_kernel<NT, WAVES, ISLOTS>), dim3(tiles), dim3(G::THREADS), shm, s, a);

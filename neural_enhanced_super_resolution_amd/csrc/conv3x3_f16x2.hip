@@ -641,12 +641,10 @@ template <int RW, int ISLOTS, int DMAW, int NACC, int NT>
 hipError_t launch_split(const ConvArgs& a, hipStream_t s) {
     typedef Geo<RW, DMAW> G;
     constexpr size_t shm = (size_t)ISLOTS * G::IN_BYTES + 2 * (size_t)(W_ITEMS1 * NT * 16);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_f16x2_kernel<RW, ISLOTS, DMAW, NACC, NT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    static unsigned long long attr_done = 0;
+    {
+        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_f16x2_kernel<RW, ISLOTS, DMAW, NACC, NT>), shm, attr_done);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const long total = (long)((a.w_ + TW - 1) / TW) * ((a.h + G::TH - 1) / G::TH) * a.n * (a.coutp / (32 * NT));
     if (total <= 0) return hipSuccess;

@@ -326,12 +326,10 @@ template <bool BF, int NT, int WV>
 hipError_t launch_nt(const ConvArgs& a, hipStream_t s) {
     constexpr int TH_ = 2 * WV;
     constexpr size_t shm = 3 * (2 * (TH_ + 2) * PW + 9 * 2 * 32 * NT) * sizeof(f32x4);
-    static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the opt-in once per kernel
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<BF, NT, WV>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    static unsigned long long attr_done = 0;
+    {
+        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_mfma_kernel<BF, NT, WV>), shm, attr_done);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const int tiles = ((a.w_ + TW - 1) / TW) * ((a.h + TH_ - 1) / TH_) * a.n;
     if (tiles <= 0) return hipSuccess;
@@ -465,11 +463,14 @@ __global__ __launch_bounds__(256, 2) void trunk_persist_kernel(TrunkArgs t) {
 
 template <bool BF>
 hipError_t launch_trunk(const TrunkArgs& t, hipStream_t s) {
-    static int max_blocks = -1;   // co-resident workgroups on this device
-    if (max_blocks < 0) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&trunk_persist_kernel<BF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)TRUNK_SHM);
+    static int max_blocks = -1;   // co-resident workgroups (all devices of a node are the same part)
+    static unsigned long long attr_done = 0;
+    {
+        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&trunk_persist_kernel<BF>), TRUNK_SHM, attr_done);
         if (e != hipSuccess) return e;
+    }
+    if (max_blocks < 0) {
+        hipError_t e;
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
         if ((e = hipGetDevice(&dev)) != hipSuccess) return e;

@@ -383,12 +383,10 @@ __global__ __launch_bounds__(128 * CW, 2) void conv3x3_wino_f32_kernel(ConvArgs 
 template <int NT, int STAGES, int CW>
 hipError_t launch_wino(const ConvArgs& a, hipStream_t s) {
     constexpr size_t shm = STAGES * (size_t)(IN_BYTES + 16 * (16 * NT * CW) * 32);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_wino_f32_kernel<NT, STAGES, CW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    static unsigned long long attr_done = 0;
+    {
+        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_wino_f32_kernel<NT, STAGES, CW>), shm, attr_done);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const int tiles = ((a.w_ + TW - 1) / TW) * ((a.h + TH - 1) / TH) * a.n;
     if (tiles <= 0) return hipSuccess;

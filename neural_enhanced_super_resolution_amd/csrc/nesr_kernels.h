@@ -20,6 +20,19 @@ struct Map {
     long long chunk;  // elements between consecutive K-groups
 };
 
+// More than 64 KiB of dynamic LDS needs an opt-in per kernel AND per device: a process may hold contexts on
+// several GPUs (nesr_create's device_id), and the attribute belongs to the device's copy of the code object.
+// `done` is the launcher's static bitmask of devices already set (a benign race: the call is idempotent).
+inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, unsigned long long& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 64 && ((done >> dev) & 1ull)) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && dev < 64) done |= 1ull << dev;
+    return e;
+}
+
 // One fused 3x3 / stride 1 / zero-pad 1 convolution (torch.cat-free dense block: conv k reads
 // channels [0, cin) and writes channels [out_coff, out_coff + coutp) of the same buffer).
 struct ConvArgs {
