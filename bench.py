@@ -44,6 +44,8 @@ WORKLOADS = {
     "c2-bf16": dict(h=512, w=512, scale=2, dtype="bf16", tile=0, tile_pad=10, desc="512x512->1024x1024 RealESRGAN_x2plus bf16 single tile"),
     "c3": dict(h=2160, w=3840, scale=2, dtype="bf16", tile=512, tile_pad=10, desc="3840x2160->7680x4320 RealESRGAN_x2plus bf16, tile 512/10"),
     "c3-f32": dict(h=2160, w=3840, scale=2, dtype="f32", tile=512, tile_pad=10, desc="3840x2160->7680x4320 RealESRGAN_x2plus fp32, tile 512/10"),
+    "c3-exact": dict(h=2160, w=3840, scale=2, dtype="f32", tile=0, tile_pad=10, banded=True,
+                     desc="3840x2160->7680x4320 RealESRGAN_x2plus fp32, untiled (tile=0, as nesr/nesr.py:224); N>1: row bands + RCCL apron exchange per RDB"),
     "c4": dict(h=1080, w=1920, scale=4, dtype="bf16", tile=512, tile_pad=10, desc="1920x1080->7680x4320 RealESRGAN_x4plus bf16, tile 512/10"),
 }
 
@@ -153,6 +155,13 @@ def main():
     up.pre_process(np.ascontiguousarray(frame[:, :, ::-1].astype(np.float32) / 255.0))
     x = up.img
 
+    banded_frame = bool(wl.get("banded")) and world > 1
+    if banded_frame:
+        # one untiled frame for the whole job: row bands, apron rows exchanged point-to-point before every RDB
+        # (banded.py), result gathered on rank 0 (strong scaling); bitwise the single-GPU untiled result
+        from neural_enhanced_super_resolution_amd import banded
+        frame = synthetic_frame(wl["h"], wl["w"], seed=0)
+        band = torch.from_numpy(banded.scatter_band(frame, rank, world, net.unshuffle)).to(dev)
     sharded_frame = wl["tile"] > 0 and world > 1
     if sharded_frame:
         # one frame for the whole job: tiles of upstream's grid sharded over the ranks, overlap rows
@@ -162,6 +171,8 @@ def main():
         band = torch.from_numpy(sharded.scatter_rows(frame, rank, world)).to(dev)
 
     def step():
+        if banded_frame:
+            return banded.enhance_banded(up, band, (wl["h"], wl["w"]))
         if sharded_frame:
             return sharded.enhance_sharded(up, band, (wl["h"], wl["w"]))
         if wl["tile"] > 0:
@@ -196,7 +207,7 @@ def main():
         elapsed = float(t.item())
 
     out_mp = wl["h"] * netscale * wl["w"] * netscale / 1e6
-    frames_per_step = 1 if sharded_frame else world
+    frames_per_step = 1 if (sharded_frame or banded_frame) else world
     value = frames_per_step * args.steps * out_mp / elapsed
     frame_flops = net.forward_flops(1, wl["h"], wl["w"])
 
@@ -204,11 +215,12 @@ def main():
         "metric": "output megapixels/sec, RealESRGAN_x2plus x2 upscale" if scale == 2 else "output megapixels/sec, RealESRGAN_x4plus x4 upscale",
         "value": round(value, 3), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-        "scaling": "strong" if sharded_frame else "weak",
+        "scaling": "strong" if (sharded_frame or banded_frame) else "weak",
         "vs_baseline": None, "dtype": algo["dtype"] if algo else dtype, "data": "synthetic (seeded frames, seeded random-init weights)",
         "config": {"workload": f"{args.workload}: {wl['desc']}",
                    "frames_per_step": frames_per_step,
                    "partition": ("tiles of the 512/10 grid sharded over ranks, RCCL p2p overlap rows, gather on rank 0" if sharded_frame
+                                 else "row bands of one untiled frame, RCCL p2p apron rows before every RDB, gather on rank 0" if banded_frame
                                  else "independent frames, no data-path collective"),
                    "boundary": "RRDBNet.forward on the device-resident NCHW f32 tensor of RealESRGANer.pre_process",
                    "tflop_per_frame": round(frame_flops / 1e12, 4)},

@@ -110,6 +110,28 @@ int nesr_preferred_batch(const nesr_ctx* ctx, int H, int W, int max_batch);
 double nesr_forward_flops(const nesr_ctx* ctx, int N, int H, int W);
 
 /*
+ * Banded evaluation: the exact (seamless) multi-GPU mode of SURVEY.md section 8(e).  Stands behind the same
+ * reference call as nesr_forward -- `self.model(img)` on a whole frame, nesr/nesr.py:887-891 with tile=0
+ * (nesr/nesr.py:224) -- when the frame is split into row bands, one per rank.  A rank holds its band plus `apron`
+ * rows of its neighbours (N = 1, input [1,C,H,W] NCHW f32 including the apron rows) and runs the stages in order:
+ *     nesr_band_begin                       pixel_unshuffle + conv_first
+ *     nesr_band_rdb(i), i = 0 .. 3*num_block-1   the five convs of RDB i (RRDB i/3, dense block i%3)
+ *     nesr_band_tail                        conv_body .. conv_last  ->  [1,num_out_ch,4h,4w] f32
+ * Every 3x3 conv spoils one more row at a band edge that is not a frame edge, so before a stage the caller
+ * overwrites the apron rows of the feature map the stage reads with the neighbours' band rows: buffer i%3 before
+ * nesr_band_rdb(i) (5 rows), buffers 0 and 3 before nesr_band_tail (3 rows).  nesr_band_rows moves rows
+ * [row0, row0+nrows) of the num_feat-channel slice of a buffer (0,1,2 = the rotating dense-block buffers, 3 = the
+ * conv_first output kept for the trunk skip) to/from a contiguous staging buffer of nrows * nesr_band_row_bytes
+ * bytes, in the context's own element layout (opaque: only ever handed to another rank's nesr_band_rows).
+ * neural_enhanced_super_resolution_amd/banded.py is the reference-side protocol (RCCL point-to-point).
+ */
+int nesr_band_begin(nesr_ctx* ctx, const void* x_dev, int C, int H, int W, void* hip_stream);
+int nesr_band_rdb(nesr_ctx* ctx, int index, void* hip_stream);
+int nesr_band_tail(nesr_ctx* ctx, void* y_dev, void* hip_stream);
+size_t nesr_band_row_bytes(const nesr_ctx* ctx);
+int nesr_band_rows(nesr_ctx* ctx, int buffer, int row0, int nrows, void* staging_dev, int write, void* hip_stream);
+
+/*
  * Timing hook for bench.py's roofline leg: when enabled, forward() brackets the dominant kernel
  * family (the dense-block 3x3 convs) with hipEvents on the caller's stream; nesr_kernel_time_ms
  * returns the accumulated elapsed ms and launch count since the last call (synchronises those

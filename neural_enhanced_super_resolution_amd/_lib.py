@@ -29,6 +29,11 @@ SIGNATURES = {
     "nesr_reserve": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int]),
     "nesr_preferred_batch": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int]),
     "nesr_forward_flops": (_c.c_double, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int]),
+    "nesr_band_begin": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    "nesr_band_rdb": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p]),
+    "nesr_band_tail": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "nesr_band_row_bytes": (_c.c_size_t, [_c.c_void_p]),
+    "nesr_band_rows": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p]),
     "nesr_set_kernel_timing": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "nesr_kernel_time_ms": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_double)]),
     "nesr_check_status": (_c.c_int, [_c.c_void_p]),

@@ -51,6 +51,19 @@ struct Layer {
 
 }  // namespace
 
+// byte offsets of the feature maps inside the workspace
+struct WsLayout {
+    size_t in, f, a, b, c, u1, u2, u3, sync, total;
+    int sync_words;
+};
+// geometry + workspace views of one evaluation (see fw_* below)
+struct FwState {
+    int N = 0, h = 0, w = 0;      // batch, internal (trunk) height and width
+    WsLayout L;
+    nesr::Map m_in, m_f, m_t, m_u1, m_u2;
+    char* buf[3] = {nullptr, nullptr, nullptr};
+};
+
 struct nesr_ctx {
     int device = 0, cin0 = 3, unshuffle = 0, nf = 64, nb = 23, gc = 32, nout = 3, dtype = 0;
     bool winograd = false;   // f32 feature-map convs by Winograd F(2x2,3x3) (NESR_DTYPE_F32_WINOGRAD)
@@ -64,6 +77,8 @@ struct nesr_ctx {
     TrunkLayer* d_trunk = nullptr;
     unsigned* last_sync = nullptr;   // abort word of the most recent persistent launch   // device copy of the trunk's layer table (persistent trunk kernel)
     int trunk_mode = 0;              // 0 auto, 1 per-layer launches, 2 persistent kernel
+    FwState band;                    // the banded evaluation in progress (nesr_band_*)
+    bool band_valid = false;
     // kernel timing hook
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pending;
@@ -81,11 +96,6 @@ struct nesr_ctx {
 namespace {
 
 int layer_id(const nesr_ctx* c, int b, int r, int k) { return 1 + (b * 3 + r) * 5 + k; }  // r,k zero based
-
-struct WsLayout {
-    size_t in, f, a, b, c, u1, u2, u3, sync, total;
-    int sync_words;
-};
 
 WsLayout ws_layout(const nesr_ctx* c, int N, int h, int w) {
     const size_t es = c->esize();
@@ -170,9 +180,9 @@ Map make_map(int kind, int channels, size_t pixels) {
 
 double conv_flops(const Layer& L, double pixels) { return 2.0 * 9.0 * L.cin * L.cout * pixels; }
 
-// The forward graph.  x -> y; exactly one of (x_f32, x_u8) and one of (y_f32, y_u8) is set.
-int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, int N, int C, int H, int W,
-                float* y_f32, uint8_t* y_u8, int round_mode, hipStream_t s) {
+// ---- the forward graph in stages (whole-frame forward = all of them in order; the banded multi-GPU mode
+// runs them one at a time with a row exchange in between)
+int fw_setup(nesr_ctx* c, int N, int C, int H, int W, FwState& F) {
     if (!c->finalized) return fail(NESR_ERR_STATE, "weights not finalized (call nesr_finalize_weights)");
     const int u = c->ufac();
     if (N <= 0 || H <= 0 || W <= 0) return fail(NESR_ERR_ARG, "empty input");
@@ -181,43 +191,127 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
                                       std::to_string(c->cin0) + " after unshuffle " + std::to_string(u));
     if (H % u || W % u) return fail(NESR_ERR_ARG, "H and W must be multiples of the unshuffle factor");
     HIP_TRY(hipSetDevice(c->device));
-    const int h = H / u, w = W / u;
-    const WsLayout L = ws_layout(c, N, h, w);
-    int rc = ensure_ws(c, L.total);
+    F.N = N; F.h = H / u; F.w = W / u;
+    F.L = ws_layout(c, N, F.h, F.w);
+    int rc = ensure_ws(c, F.L.total);
     if (rc) return rc;
-    char* ws = c->ws;
-    const int nf = c->nf, gc = c->gc, ct = c->ct();
-    const int bf = c->kind();
+    const int kind = c->kind();
+    const size_t P1 = (size_t)N * F.h * F.w;
+    F.m_in = make_map(kind, c->layers[0].cin_p, P1);
+    F.m_f = make_map(kind, c->nf, P1);
+    F.m_t = make_map(kind, c->ct(), P1);
+    F.m_u1 = make_map(kind, c->nf, P1 * 4);
+    F.m_u2 = make_map(kind, c->nf, P1 * 16);
+    F.buf[0] = c->ws + F.L.a; F.buf[1] = c->ws + F.L.b; F.buf[2] = c->ws + F.L.c;
+    return NESR_OK;
+}
 
+// pack (pixel_unshuffle, layout, u8 normalisation) + conv_first: IN -> P.x0 and F (feat is needed again after the trunk)
+int fw_first(nesr_ctx* c, const FwState& F, const float* x_f32, const uint8_t* x_u8, int flip, int C, int H, int W, hipStream_t s) {
+    char* ws = c->ws;
     PackArgs p;
     std::memset(&p, 0, sizeof(p));
     p.src = x_u8 ? static_cast<const void*>(x_u8) : static_cast<const void*>(x_f32);
     p.src_u8 = x_u8 ? 1 : 0;
     p.flip = flip;
-    p.n = N; p.c = C; p.hin = H; p.win = W;
-    p.unshuffle = u;
-    const size_t P1 = (size_t)N * h * w;
-    const Map m_in = make_map(bf, c->layers[0].cin_p, P1), m_f = make_map(bf, nf, P1), m_t = make_map(bf, ct, P1);
-    const Map m_u1 = make_map(bf, nf, P1 * 4), m_u2 = make_map(bf, nf, P1 * 16);
-    p.dst = ws + L.in;
-    p.dst_map = m_in;
+    p.n = F.N; p.c = C; p.hin = H; p.win = W;
+    p.unshuffle = c->ufac();
+    p.dst = ws + F.L.in;
+    p.dst_map = F.m_in;
     p.cp = c->layers[0].cin_p;
-    p.bf16 = bf;
+    p.bf16 = c->kind();
     HIP_TRY(launch_pack_input(p, s));
+    ConvArgs a = base_args(c, c->layers[0], F.N, F.h, F.w);
+    a.in = ws + F.L.in; a.in_map = F.m_in;
+    a.out = ws + F.L.a; a.out_map = F.m_t; a.out_coff = 0;
+    a.out2 = ws + F.L.f; a.out2_map = F.m_f;
+    HIP_TRY(launch_conv(c, a, s, &c->layers[0]));
+    return NESR_OK;
+}
 
-    // conv_first: IN -> A.x0 and F (feat is needed again after the trunk)
-    {
-        ConvArgs a = base_args(c, c->layers[0], N, h, w);
-        a.in = ws + L.in; a.in_map = m_in;
-        a.out = ws + L.a; a.out_map = m_t; a.out_coff = 0;
-        a.out2 = ws + L.f; a.out2_map = m_f;
-        HIP_TRY(launch_conv(c, a, s, &c->layers[0]));
+// RDB r (0..2) of RRDB b.  Buffers P,Q,R hold x0|x1|x2|x3|x4 of RDB1,2,3; RDB3's conv5 applies both residuals
+// (x5*0.2+x0 then *0.2 + RRDB input) and lands in P.x0 in place, so every RRDB starts and ends in P.
+int fw_rdb(nesr_ctx* c, const FwState& F, int b, int r, hipStream_t s) {
+    const int nf = c->nf, gc = c->gc;
+    const double px = (double)F.N * F.h * F.w;
+    char* cur = F.buf[r];
+    for (int k = 0; k < 4; ++k) {
+        const Layer& Ly = c->layers[layer_id(c, b, r, k)];
+        ConvArgs a = base_args(c, Ly, F.N, F.h, F.w);
+        a.in = cur; a.in_map = F.m_t;
+        a.out = cur; a.out_map = F.m_t; a.out_coff = nf + k * gc;
+        a.lrelu = 1;
+        HIP_TRY(launch_conv(c, a, s, &Ly));
+        if (c->timing) c->timed_flops += conv_flops(Ly, px);
     }
+    const Layer& L5 = c->layers[layer_id(c, b, r, 4)];
+    ConvArgs a = base_args(c, L5, F.N, F.h, F.w);
+    a.in = cur; a.in_map = F.m_t;
+    a.res1 = cur; a.res1_map = F.m_t; a.s1 = 0.2f;
+    if (r < 2) {
+        a.out = F.buf[r + 1];
+    } else {
+        a.out = F.buf[0];
+        a.res2 = F.buf[0]; a.res2_map = F.m_t; a.s2 = 0.2f;
+    }
+    a.out_map = F.m_t; a.out_coff = 0;
+    HIP_TRY(launch_conv(c, a, s, &L5));
+    if (c->timing) c->timed_flops += conv_flops(L5, px);
+    return NESR_OK;
+}
 
-    // trunk: 23 x RRDB.  Buffers P,Q,R hold x0|x1|x2|x3|x4 of RDB1,2,3; RDB3's conv5 applies both
-    // residuals (x5*0.2+x0 then *0.2 + RRDB input) and lands in P.x0 in place, so every RRDB
-    // starts and ends in P.
-    char* buf[3] = {ws + L.a, ws + L.b, ws + L.c};
+// conv_body + trunk skip, the two nearest-x2 + conv stages, conv_hr, conv_last
+int fw_tail(nesr_ctx* c, const FwState& F, float* y_f32, uint8_t* y_u8, int flip, int round_mode, hipStream_t s) {
+    char* ws = c->ws;
+    const int N = F.N, h = F.h, w = F.w;
+    const int tail = 1 + c->nb * 15;
+    {   // feat = feat + conv_body(trunk)   (in place on F)
+        ConvArgs a = base_args(c, c->layers[tail], N, h, w);
+        a.in = F.buf[0]; a.in_map = F.m_t;
+        a.out = ws + F.L.f; a.out_map = F.m_f;
+        a.res1 = ws + F.L.f; a.res1_map = F.m_f; a.s1 = 1.0f;
+        HIP_TRY(launch_conv(c, a, s, &c->layers[tail]));
+    }
+    {   // lrelu(conv_up1(nearest2x(feat)))
+        ConvArgs a = base_args(c, c->layers[tail + 1], N, 2 * h, 2 * w);
+        a.in = ws + F.L.f; a.in_map = F.m_f; a.in_h = h; a.in_w = w; a.up = 1;
+        a.out = ws + F.L.u1; a.out_map = F.m_u1; a.lrelu = 1;
+        HIP_TRY(launch_conv(c, a, s, &c->layers[tail + 1]));
+    }
+    {   // lrelu(conv_up2(nearest2x(feat)))
+        ConvArgs a = base_args(c, c->layers[tail + 2], N, 4 * h, 4 * w);
+        a.in = ws + F.L.u1; a.in_map = F.m_u1; a.in_h = 2 * h; a.in_w = 2 * w; a.up = 1;
+        a.out = ws + F.L.u2; a.out_map = F.m_u2; a.lrelu = 1;
+        HIP_TRY(launch_conv(c, a, s, &c->layers[tail + 2]));
+    }
+    {   // lrelu(conv_hr(feat))
+        ConvArgs a = base_args(c, c->layers[tail + 3], N, 4 * h, 4 * w);
+        a.in = ws + F.L.u2; a.in_map = F.m_u2;
+        a.out = ws + F.L.u3; a.out_map = F.m_u2; a.lrelu = 1;
+        HIP_TRY(launch_conv(c, a, s, &c->layers[tail + 3]));
+    }
+    {   // conv_last -> planar f32 NCHW, or clamped + quantised u8 HWC
+        ConvArgs a = base_args(c, c->layers[tail + 4], N, 4 * h, 4 * w);
+        a.in = ws + F.L.u3; a.in_map = F.m_u2;
+        a.cout_real = c->nout;
+        a.out_nchw = y_f32;
+        a.out_u8 = y_u8;
+        a.u8_flip = flip;
+        a.u8_round = round_mode;
+        HIP_TRY(launch_conv(c, a, s, &c->layers[tail + 4]));
+    }
+    return NESR_OK;
+}
+
+// The whole forward.  x -> y; exactly one of (x_f32, x_u8) and one of (y_f32, y_u8) is set.
+int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, int N, int C, int H, int W,
+                float* y_f32, uint8_t* y_u8, int round_mode, hipStream_t s) {
+    FwState F;
+    int rc = fw_setup(c, N, C, H, W, F);
+    if (rc) return rc;
+    c->band_valid = false;   // the workspace no longer holds a banded evaluation
+    if ((rc = fw_first(c, F, x_f32, x_u8, flip, C, H, W, s))) return rc;
+
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (c->timing) {
         if (!c->ev_free.empty()) {
@@ -229,103 +323,36 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
         }
         HIP_TRY(hipEventRecord(ev0, s));
     }
-    const double px = (double)N * h * w;
     const bool persist = c->trunk_mode == 2;   // opt-in (NESR_TRUNK=persist): measured slower at 2 tiles/CU, see DESIGN.md
     if (persist && c->nb > 0) {
         // one cooperative launch for all 15*nb dense-block convs (tile-level dataflow sync)
-        unsigned* sync = reinterpret_cast<unsigned*>(ws + L.sync);
-        HIP_TRY(hipMemsetAsync(sync, 0, (size_t)L.sync_words * 4, s));
+        unsigned* sync = reinterpret_cast<unsigned*>(c->ws + F.L.sync);
+        HIP_TRY(hipMemsetAsync(sync, 0, (size_t)F.L.sync_words * 4, s));
         TrunkArgs t;
         std::memset(&t, 0, sizeof(t));
         t.layers = c->d_trunk;
         t.nlayers = c->nb * 15;
-        t.buf[0] = buf[0]; t.buf[1] = buf[1]; t.buf[2] = buf[2];
-        t.map = m_t;
-        t.n = N; t.h = h; t.w = w;
+        t.buf[0] = F.buf[0]; t.buf[1] = F.buf[1]; t.buf[2] = F.buf[2];
+        t.map = F.m_t;
+        t.n = N; t.h = F.h; t.w = F.w;
         t.progress = sync + 64;
         t.abort_flag = sync;
         t.zeros = c->d_weights;
-        HIP_TRY(launch_trunk_persist(t, bf == 1, s));
+        HIP_TRY(launch_trunk_persist(t, c->kind() == 1, s));
         c->last_sync = sync;
         if (c->timing)
-            for (int i = 0; i < c->nb * 15; ++i) c->timed_flops += conv_flops(c->layers[1 + i], px);
+            for (int i = 0; i < c->nb * 15; ++i) c->timed_flops += conv_flops(c->layers[1 + i], (double)N * F.h * F.w);
     } else {
-        for (int b = 0; b < c->nb; ++b) {
-            for (int r = 0; r < 3; ++r) {
-                char* cur = buf[r];
-                for (int k = 0; k < 4; ++k) {
-                    const Layer& Ly = c->layers[layer_id(c, b, r, k)];
-                    ConvArgs a = base_args(c, Ly, N, h, w);
-                    a.in = cur; a.in_map = m_t;
-                    a.out = cur; a.out_map = m_t; a.out_coff = nf + k * gc;
-                    a.lrelu = 1;
-                    HIP_TRY(launch_conv(c, a, s, &Ly));
-                    if (c->timing) c->timed_flops += conv_flops(Ly, px);
-                }
-                const Layer& L5 = c->layers[layer_id(c, b, r, 4)];
-                ConvArgs a = base_args(c, L5, N, h, w);
-                a.in = cur; a.in_map = m_t;
-                a.res1 = cur; a.res1_map = m_t; a.s1 = 0.2f;
-                if (r < 2) {
-                    a.out = buf[r + 1];
-                } else {
-                    a.out = buf[0];
-                    a.res2 = buf[0]; a.res2_map = m_t; a.s2 = 0.2f;
-                }
-                a.out_map = m_t; a.out_coff = 0;
-                HIP_TRY(launch_conv(c, a, s, &L5));
-                if (c->timing) c->timed_flops += conv_flops(L5, px);
-            }
-        }
+        for (int b = 0; b < c->nb; ++b)
+            for (int r = 0; r < 3; ++r)
+                if ((rc = fw_rdb(c, F, b, r, s))) return rc;
     }
     if (c->timing) {
         HIP_TRY(hipEventRecord(ev1, s));
         c->ev_pending.emplace_back(ev0, ev1);
         c->timed_launches += (int64_t)c->nb * 15;
     }
-
-    const int tail = 1 + c->nb * 15;
-    // feat = feat + conv_body(trunk)   (in place on F)
-    {
-        ConvArgs a = base_args(c, c->layers[tail], N, h, w);
-        a.in = buf[0]; a.in_map = m_t;
-        a.out = ws + L.f; a.out_map = m_f;
-        a.res1 = ws + L.f; a.res1_map = m_f; a.s1 = 1.0f;
-        HIP_TRY(launch_conv(c, a, s, &c->layers[tail]));
-    }
-    // lrelu(conv_up1(nearest2x(feat)))
-    {
-        ConvArgs a = base_args(c, c->layers[tail + 1], N, 2 * h, 2 * w);
-        a.in = ws + L.f; a.in_map = m_f; a.in_h = h; a.in_w = w; a.up = 1;
-        a.out = ws + L.u1; a.out_map = m_u1; a.lrelu = 1;
-        HIP_TRY(launch_conv(c, a, s, &c->layers[tail + 1]));
-    }
-    // lrelu(conv_up2(nearest2x(feat)))
-    {
-        ConvArgs a = base_args(c, c->layers[tail + 2], N, 4 * h, 4 * w);
-        a.in = ws + L.u1; a.in_map = m_u1; a.in_h = 2 * h; a.in_w = 2 * w; a.up = 1;
-        a.out = ws + L.u2; a.out_map = m_u2; a.lrelu = 1;
-        HIP_TRY(launch_conv(c, a, s, &c->layers[tail + 2]));
-    }
-    // lrelu(conv_hr(feat))
-    {
-        ConvArgs a = base_args(c, c->layers[tail + 3], N, 4 * h, 4 * w);
-        a.in = ws + L.u2; a.in_map = m_u2;
-        a.out = ws + L.u3; a.out_map = m_u2; a.lrelu = 1;
-        HIP_TRY(launch_conv(c, a, s, &c->layers[tail + 3]));
-    }
-    // conv_last -> planar f32 NCHW, or clamped + quantised u8 HWC
-    {
-        ConvArgs a = base_args(c, c->layers[tail + 4], N, 4 * h, 4 * w);
-        a.in = ws + L.u3; a.in_map = m_u2;
-        a.cout_real = c->nout;
-        a.out_nchw = y_f32;
-        a.out_u8 = y_u8;
-        a.u8_flip = flip;
-        a.u8_round = round_mode;
-        HIP_TRY(launch_conv(c, a, s, &c->layers[tail + 4]));
-    }
-    return NESR_OK;
+    return fw_tail(c, F, y_f32, y_u8, flip, round_mode, s);
 }
 
 }  // namespace
@@ -637,6 +664,70 @@ void nesr_destroy(nesr_ctx* c) {
     if (c->d_weights) (void)hipFree(c->d_weights);
     if (c->d_trunk) (void)hipFree(c->d_trunk);
     delete c;
+}
+
+// ---- banded evaluation (exact multi-GPU mode: one row band of the frame per rank, SURVEY.md section 8(e) mode 2).
+// The caller runs the stages in order and refreshes the apron rows of the feature map each stage reads
+// (nesr_band_rows) with its neighbours' band rows in between; banded.py holds that protocol.
+int nesr_band_begin(nesr_ctx* c, const void* x_dev, int C, int H, int W, void* stream) {
+    if (!c || !x_dev) return fail(NESR_ERR_ARG, "null argument");
+    c->band_valid = false;
+    int rc = fw_setup(c, 1, C, H, W, c->band);
+    if (rc) return rc;
+    if ((rc = fw_first(c, c->band, static_cast<const float*>(x_dev), nullptr, 0, C, H, W, static_cast<hipStream_t>(stream)))) return rc;
+    c->band_valid = true;
+    return NESR_OK;
+}
+
+int nesr_band_rdb(nesr_ctx* c, int index, void* stream) {
+    if (!c) return fail(NESR_ERR_ARG, "null ctx");
+    if (!c->band_valid) return fail(NESR_ERR_STATE, "nesr_band_begin has not run (or a whole-frame forward reused the workspace)");
+    if (index < 0 || index >= 3 * c->nb) return fail(NESR_ERR_ARG, "RDB index out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    return fw_rdb(c, c->band, index / 3, index % 3, static_cast<hipStream_t>(stream));
+}
+
+int nesr_band_tail(nesr_ctx* c, void* y_dev, void* stream) {
+    if (!c || !y_dev) return fail(NESR_ERR_ARG, "null argument");
+    if (!c->band_valid) return fail(NESR_ERR_STATE, "nesr_band_begin has not run (or a whole-frame forward reused the workspace)");
+    HIP_TRY(hipSetDevice(c->device));
+    return fw_tail(c, c->band, static_cast<float*>(y_dev), nullptr, 0, 0, static_cast<hipStream_t>(stream));
+}
+
+size_t nesr_band_row_bytes(const nesr_ctx* c) {
+    if (!c || !c->band_valid) return 0;
+    return (size_t)c->band.w * c->nf * c->esize();
+}
+
+int nesr_band_rows(nesr_ctx* c, int buffer, int row0, int nrows, void* staging_dev, int write, void* stream) {
+    if (!c || !staging_dev) return fail(NESR_ERR_ARG, "null argument");
+    if (!c->band_valid) return fail(NESR_ERR_STATE, "nesr_band_begin has not run (or a whole-frame forward reused the workspace)");
+    const FwState& F = c->band;
+    if (buffer < 0 || buffer > 3 || row0 < 0 || nrows < 0 || row0 + nrows > F.h) return fail(NESR_ERR_ARG, "bad buffer / row range");
+    if (nrows == 0) return NESR_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* base = buffer < 3 ? F.buf[buffer] : c->ws + F.L.f;
+    const Map& m = buffer < 3 ? F.m_t : F.m_f;
+    char* stg = static_cast<char*>(staging_dev);
+    const int kind = c->kind();
+    if (kind == 0) {
+        // NHWC f32: channels [0, nf) of every pixel of the rows; the dense-block buffers have ct channels per pixel
+        const size_t spitch = (size_t)m.pix * 4, width = (size_t)c->nf * 4, rows = (size_t)nrows * F.w;
+        char* src = base + (size_t)row0 * F.w * spitch;
+        if (write) HIP_TRY(hipMemcpy2DAsync(src, spitch, stg, width, width, rows, hipMemcpyDeviceToDevice, s));
+        else HIP_TRY(hipMemcpy2DAsync(stg, width, src, spitch, width, rows, hipMemcpyDeviceToDevice, s));
+        return NESR_OK;
+    }
+    // channel-blocked: the rows of one 16-channel chunk are one contiguous span; staging = [chunk][rows][w][pixel bytes]
+    const size_t pixbytes = (size_t)m.pix * 2, span = (size_t)nrows * F.w * pixbytes;
+    for (int ch = 0; ch < c->nf / 16; ++ch) {
+        char* src = base + (size_t)ch * (size_t)m.chunk * 2 + (size_t)row0 * F.w * pixbytes;
+        char* dst = stg + (size_t)ch * span;
+        if (write) HIP_TRY(hipMemcpyAsync(src, dst, span, hipMemcpyDeviceToDevice, s));
+        else HIP_TRY(hipMemcpyAsync(dst, src, span, hipMemcpyDeviceToDevice, s));
+    }
+    return NESR_OK;
 }
 
 int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, int H, int W, const float* w_host,

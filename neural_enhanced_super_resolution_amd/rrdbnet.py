@@ -290,6 +290,76 @@ class RRDBNet(nn.Module):
         for ctx in handles:
             _lib.check(_lib.load().nesr_set_kernel_timing(ctx, 1 if enable else 0), "nesr_set_kernel_timing")
 
+    # ---- banded evaluation (banded.py: one row band of the frame per rank, SURVEY.md section 8(e) mode 2) ----
+    @property
+    def num_rdb(self):
+        return 3 * self.num_block
+
+    @property
+    def unshuffle(self):
+        """Input rows per internal (trunk) row: 2 for scale=2, 4 for scale=1, else 1."""
+        return {2: 2, 1: 4}.get(self.scale, 1)
+
+    @torch.no_grad()
+    def band_begin(self, x):
+        """pixel_unshuffle + conv_first on this rank's rows (band + apron): x [1, num_in_ch, H, W] float32 on a ROCm device."""
+        self._require_cuda(x)
+        if x.dim() != 4 or x.shape[0] != 1:
+            raise ValueError(f"expected [1, C, H, W], got {tuple(x.shape)}")
+        xf = x.to(torch.float32).contiguous()
+        _, c, h, w = xf.shape
+        with torch.cuda.device(xf.device):
+            ctx = self._context(xf.device)
+            stream = torch.cuda.current_stream(xf.device).cuda_stream
+            _lib.check(_lib.load().nesr_band_begin(ctx, ctypes.c_void_p(xf.data_ptr()), c, h, w, ctypes.c_void_p(stream)), "nesr_band_begin")
+        self._band = (xf.device, h // self.unshuffle, w // self.unshuffle)
+
+    def _band_call(self):
+        if getattr(self, "_band", None) is None or self._ctx is None:
+            raise RuntimeError("band_begin has not run")
+        dev = self._band[0]
+        return self._ctx[0], dev, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    @torch.no_grad()
+    def band_rdb(self, index):
+        """The five convs of RDB `index` (0 .. num_rdb-1) on the band image."""
+        ctx, dev, stream = self._band_call()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().nesr_band_rdb(ctx, int(index), stream), "nesr_band_rdb")
+
+    @torch.no_grad()
+    def band_tail(self):
+        """conv_body .. conv_last -> [1, num_out_ch, 4 h, 4 w] float32 (h, w = internal size of the band image)."""
+        ctx, dev, stream = self._band_call()
+        _, h, w = self._band
+        with torch.cuda.device(dev):
+            y = torch.empty((1, self.num_out_ch, 4 * h, 4 * w), dtype=torch.float32, device=dev)
+            _lib.check(_lib.load().nesr_band_tail(ctx, ctypes.c_void_p(y.data_ptr()), stream), "nesr_band_tail")
+        return y
+
+    @torch.no_grad()
+    def band_rows(self, buffer, row0, nrows):
+        """Internal rows [row0, row0+nrows) of the num_feat-channel slice of `buffer` (0..2 dense-block buffers,
+        3 = conv_first output) as an opaque uint8 tensor (the context's own element layout)."""
+        ctx, dev, stream = self._band_call()
+        lib = _lib.load()
+        with torch.cuda.device(dev):
+            out = torch.empty(int(nrows) * int(lib.nesr_band_row_bytes(ctx)), dtype=torch.uint8, device=dev)
+            _lib.check(lib.nesr_band_rows(ctx, int(buffer), int(row0), int(nrows), ctypes.c_void_p(out.data_ptr()), 0, stream), "nesr_band_rows")
+        return out
+
+    @torch.no_grad()
+    def band_set_rows(self, buffer, row0, rows):
+        """Inverse of band_rows: overwrites the rows with another rank's band_rows() bytes."""
+        ctx, dev, stream = self._band_call()
+        lib = _lib.load()
+        rb = int(lib.nesr_band_row_bytes(ctx))
+        rows = rows.to(dev).contiguous()
+        if rows.dtype != torch.uint8 or rows.numel() % rb:
+            raise ValueError("rows must be the uint8 tensor band_rows() returned on the sending rank")
+        with torch.cuda.device(dev):
+            _lib.check(lib.nesr_band_rows(ctx, int(buffer), int(row0), rows.numel() // rb, ctypes.c_void_p(rows.data_ptr()), 1, stream), "nesr_band_rows")
+
     def preferred_batch(self, device, h, w, max_batch):
         """Tiles of h x w input per forward call that fill the GPU's CUs most evenly (<= max_batch)."""
         ctx = self._context(torch.device(device))

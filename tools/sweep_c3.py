@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Sweeps RealESRGANer.tile_streams / tile_batch on the 2160p bf16 workload (values are invariant)."""
+"""Sweeps RealESRGANer.tile_streams / tile_batch on the 2160p workload (values are invariant).
+usage: tools/sweep_c3.py [bf16|f32]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -8,7 +9,7 @@ from neural_enhanced_super_resolution_amd.synth import synthetic_frame, syntheti
 
 sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=2)
 frame = synthetic_frame(2160, 3840, seed=0)
-up = RealESRGANer(scale=2, model_path={"params_ema": sd}, model=RRDBNet(3, 3, scale=2, compute_dtype="bf16"), tile=512, tile_pad=10, pre_pad=0, device="cuda")
+up = RealESRGANer(scale=2, model_path={"params_ema": sd}, model=RRDBNet(3, 3, scale=2, compute_dtype=(sys.argv[1] if len(sys.argv) > 1 else "bf16")), tile=512, tile_pad=10, pre_pad=0, device="cuda")
 up.pre_process(np.ascontiguousarray(frame[:, :, ::-1].astype(np.float32) / 255.0))
 for streams in (1, 2, 3, 4, 6):
     for batch in (6, 12, 24):
