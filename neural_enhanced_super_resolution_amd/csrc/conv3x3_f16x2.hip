@@ -288,6 +288,10 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int q = 0; q < NACC; ++q) acc16[r][nh][mt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // this lane's 8 output channels after the epilogue's permlane16 exchange, and their bias (fetched now: the
+    // latency hides under the K loop)
+    const int cb16 = 32 * cg + (g4 & 1) * 16 + (g4 >> 1) * 8;
+    const f32x4 bz0 = *reinterpret_cast<const f32x4*>(a.bias + cb16), bz1 = *reinterpret_cast<const f32x4*>(a.bias + cb16 + 4);
 
     // accumulators.  NACC == 2: [row][0] takes w_hi*x_hi, [row][1] the two cross terms (summed in the
     // epilogue): consecutive MFMAs never wait on each other's result, and the small terms add up among
@@ -470,12 +474,11 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
         // ---- epilogue of the 16x16x32 form.  C/D layout: lane (pixel j16, k-group g4) holds couts 16 mt + 4 g4 + i.
         // v_permlane16_swap of the mt = 0 / mt = 1 values leaves every lane with 8 consecutive couts of its
         // pixel: base 0 / 16 / 8 / 24 for g4 = 0 / 1 / 2 / 3 (tools/probes/mfma16_layout.hip).
-        const int cb = 32 * cg + (g4 & 1) * 16 + (g4 >> 1) * 8;
+        const int cb = cb16;
         const uint16_t* res1 = static_cast<const uint16_t*>(a.res1);
         const uint16_t* res2 = static_cast<const uint16_t*>(a.res2);
         uint16_t* out = static_cast<uint16_t*>(a.out);
         uint16_t* out2 = static_cast<uint16_t*>(a.out2);
-        const f32x4 bz0 = *reinterpret_cast<const f32x4*>(a.bias + cb), bz1 = *reinterpret_cast<const f32x4*>(a.bias + cb + 4);
 #pragma unroll
         for (int r = 0; r < RW; ++r)
 #pragma unroll
