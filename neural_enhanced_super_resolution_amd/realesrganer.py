@@ -290,6 +290,42 @@ class RealESRGANer:
         return q.contiguous().cpu().numpy()
 
     @torch.no_grad()
+    def enhance_many(self, imgs, inflight=2):
+        """``[self.enhance(img) for img in imgs]`` with up to `inflight` frames on the GPU at once.
+
+        Not part of upstream's API: a frame whose network layers are only a few hundred workgroups (512x512:
+        256-512 per layer, each launch ~4 us of fixed cost) leaves half the GPU idle; a second frame on its own HIP
+        stream and context replica fills it (bench.py's default `value`: 1.19x the one-at-a-time rate).  Frames
+        that do not take the fused 8-bit path (tiling, padding, alpha, 16 bit) are processed one at a time.
+        The results are identical to enhance()'s."""
+        imgs = list(imgs)
+        if inflight <= 1 or not imgs or not all(self._fused_u8_ok(i) for i in imgs):
+            return [self.enhance(i) for i in imgs]
+        streams = [torch.cuda.Stream(self.device) for _ in range(inflight)]
+        results, pending = [None] * len(imgs), []
+
+        def finish(entry):
+            idx, host, ev = entry
+            ev.synchronize()
+            results[idx] = (host.numpy().copy(), "RGB")
+
+        for i, img in enumerate(imgs):
+            if len(pending) >= inflight:
+                finish(pending.pop(0))
+            k = i % inflight
+            with torch.cuda.stream(streams[k]):
+                x = torch.from_numpy(np.ascontiguousarray(img)).pin_memory().to(self.device, non_blocking=True)
+                y = self.model.forward_u8(x, flip_rgb=True, round_nearest=True, slot=k)
+                host = torch.empty(y.shape, dtype=torch.uint8, pin_memory=True)
+                host.copy_(y, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            pending.append((i, host, ev))
+        for entry in pending:
+            finish(entry)
+        return results
+
+    @torch.no_grad()
     def enhance_float(self, img):
         """Everything of enhance() up to (not including) quantisation: returns (HWC float32 in
         [0,1] in BGR(A)/gray order, img_mode, max_range)."""

@@ -252,8 +252,8 @@ class RRDBNet(nn.Module):
         return y if in_dtype == torch.float32 else y.to(in_dtype)
 
     @torch.no_grad()
-    def forward_u8(self, img_hwc_u8, flip_rgb=True, round_nearest=True):
-        """Fused image path: u8 HWC [H,W,3] device tensor -> u8 HWC [H*s,W*s,3].
+    def forward_u8(self, img_hwc_u8, flip_rgb=True, round_nearest=True, slot: int = 0):
+        """Fused image path: u8 HWC [H,W,3] device tensor -> u8 HWC [H*s,W*s,3] (`slot`: context replica, see forward).
 
         flip_rgb/round_nearest = (True, True) reproduces RealESRGANer.enhance's /255, BGR<->RGB,
         clamp, x255, round; (False, False) reproduces nesr/nesr.py:851-857,894-898 (truncation)."""
@@ -264,7 +264,7 @@ class RRDBNet(nn.Module):
         h, w, _ = x.shape
         s = self.out_scale()
         with torch.cuda.device(x.device):
-            ctx = self._context(x.device)
+            ctx = self._context(x.device, slot)
             y = torch.empty((h * s, w * s, 3), dtype=torch.uint8, device=x.device)
             stream = torch.cuda.current_stream(x.device).cuda_stream
             _lib.check(_lib.load().nesr_forward_u8(ctx, ctypes.c_void_p(x.data_ptr()), h, w, ctypes.c_void_p(y.data_ptr()),

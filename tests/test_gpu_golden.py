@@ -181,3 +181,19 @@ def test_u8_device_pipeline_equals_host_float_path(cuda_device, kw, hw):
     got, mode = up.enhance(img)
     f, _, _ = up.enhance_float(img)
     assert mode == "RGB" and np.array_equal(got, (f * 255.0).round().astype(np.uint8))
+
+
+@pytest.mark.parametrize("inflight", [2, 3])
+def test_enhance_many_equals_enhance(cuda_device, inflight):
+    """Frames in flight on separate streams / context replicas: same bytes as one at a time, in order."""
+    sd = synthetic_state_dict(seed=3, num_in_ch=3, scale=2, num_block=2)
+    up = RealESRGANer(scale=2, model_path={"params_ema": sd}, model=RRDBNet(3, 3, scale=2, num_block=2), tile=0, pre_pad=0,
+                      half=False, device=cuda_device)
+    frames = [synthetic_frame(64, 96, seed=s) for s in range(5)]
+    want = [up.enhance(f) for f in frames]
+    got = up.enhance_many(frames, inflight=inflight)
+    assert len(got) == len(want)
+    for (g, gm), (w, wm) in zip(got, want):
+        assert gm == wm and np.array_equal(g, w)
+    odd = [synthetic_frame(63, 95, seed=9)]                 # needs mod-padding: falls back to enhance()
+    assert np.array_equal(up.enhance_many(odd)[0][0], up.enhance(odd[0])[0])
