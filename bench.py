@@ -227,6 +227,7 @@ def main():
     model.set_kernel_timing(dev, False)
     single = None
     if inflight > 1:
+        model.set_concurrent(False)          # one frame alone: the device is this context's
         model.set_kernel_timing(dev, True)
         model.kernel_time()
         torch.cuda.synchronize(dev)
@@ -237,6 +238,7 @@ def main():
         single = (time.perf_counter() - t1) / args.steps
         k_ms, k_launches, k_flops = model.kernel_time()
         model.set_kernel_timing(dev, False)
+        model.set_concurrent(True)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

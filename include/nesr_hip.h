@@ -131,6 +131,10 @@ int nesr_band_tail(nesr_ctx* ctx, void* y_dev, void* hip_stream);
 size_t nesr_band_row_bytes(const nesr_ctx* ctx);
 int nesr_band_rows(nesr_ctx* ctx, int buffer, int row0, int nrows, void* staging_dev, int write, void* hip_stream);
 
+/* Hint: forwards of this context run while other contexts of the process use the same device (several frames or
+ * tile groups in flight on different streams).  Changes kernel selection only, never a value. */
+int nesr_set_concurrent(nesr_ctx* ctx, int concurrent);
+
 /*
  * Timing hook for bench.py's roofline leg: when enabled, forward() brackets the dominant kernel
  * family (the dense-block 3x3 convs) with hipEvents on the caller's stream; nesr_kernel_time_ms

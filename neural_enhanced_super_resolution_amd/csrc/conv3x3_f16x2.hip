@@ -717,7 +717,10 @@ hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s) {
     }();
     static const int dmaw = [] { const char* e = getenv("NESR_SPLIT_DMAW"); return e ? atoi(e) : -1; }();
     const long t1 = (long)((a.w_ + TW - 1) / TW) * ((a.h + 7) / 8) * a.n * (a.coutp >> 5);
-    const bool producer = dmaw >= 0 ? dmaw > 0 : t1 <= cus;
+    // ... and only when this context has the device to itself: with frames in flight on other streams the 8-wave
+    // workgroups (166 registers) keep a second kernel's workgroups off the CU (2 frames in flight: 158 -> 166 MP/s
+    // without them; one frame alone: 134 -> 138 MP/s with them)
+    const bool producer = dmaw >= 0 ? dmaw > 0 : (t1 <= cus && !a.shared_device);
     constexpr int NA = WAVES == 8 ? 1 : 2;   // the 8-wave build has 128 registers per wave
     static const int d2 = [] { const char* e = getenv("NESR_SPLIT_D2"); return e ? atoi(e) : 0; }();
     if (d2 && !producer) return launch_split<RW_S, 2, 2, 1, 1>(a, s);   // two workgroups per CU, each 4 MFMA + 2 DMA waves (<= 168 registers)

@@ -77,6 +77,7 @@ struct nesr_ctx {
     TrunkLayer* d_trunk = nullptr;
     unsigned* last_sync = nullptr;   // abort word of the most recent persistent launch   // device copy of the trunk's layer table (persistent trunk kernel)
     int trunk_mode = 0;              // 0 auto, 1 per-layer launches, 2 persistent kernel
+    int shared_device = 0;           // nesr_set_concurrent: other contexts run on the device at the same time
     FwState band;                    // the banded evaluation in progress (nesr_band_*)
     bool band_valid = false;
     // kernel timing hook
@@ -165,6 +166,7 @@ ConvArgs base_args(const nesr_ctx* c, const Layer& L, int N, int h, int w) {
     a.in_w = w;
     a.s1 = a.s2 = 1.f;
     a.cout_real = 0;
+    a.shared_device = c->shared_device;
     return a;
 }
 
@@ -614,6 +616,12 @@ int nesr_preferred_batch(const nesr_ctx* c, int H, int W, int max_batch) {
     for (int b = 1; b <= max_batch; ++b)
         if (eff(b) >= best_eff - 0.02) best = b;   // the largest batch within 2 % of the best fill: fewest launches
     return best;
+}
+
+int nesr_set_concurrent(nesr_ctx* c, int concurrent) {
+    if (!c) return fail(NESR_ERR_ARG, "null ctx");
+    c->shared_device = concurrent ? 1 : 0;
+    return NESR_OK;
 }
 
 int nesr_set_kernel_timing(nesr_ctx* c, int enable) {

@@ -67,6 +67,9 @@ struct ConvArgs {
     int u8_flip, u8_round;
     // >= 16 bytes of device zeros: LDS-DMA source for out-of-image pixels (bf16 large-tile kernel)
     const void* zeros;
+    // host-side hint, not read by kernels: other contexts' launches share the device with this one (frames or tile
+    // groups in flight on several streams) -- prefer kernel forms whose workgroups leave room on a CU
+    int shared_device;
 };
 
 // f32 path: v_mfma_f32_32x32x2_f32 implicit GEMM (conv3x3_f32.hip)

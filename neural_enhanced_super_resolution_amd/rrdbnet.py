@@ -198,6 +198,9 @@ class RRDBNet(nn.Module):
                 handle = self._create(index, code)
                 self._upload(handle)
                 self._extra[slot] = (handle, index, code)
+                # replicas exist to run beside each other: tell every context of the model
+                for h in [self._ctx] + list(self._extra.values()):
+                    _lib.check(lib.nesr_set_concurrent(h[0], 1), "nesr_set_concurrent")
             return self._extra[slot][0]
         if self._ctx is None:
             handle = ctypes.c_void_p()
@@ -359,6 +362,13 @@ class RRDBNet(nn.Module):
             raise ValueError("rows must be the uint8 tensor band_rows() returned on the sending rank")
         with torch.cuda.device(dev):
             _lib.check(lib.nesr_band_rows(ctx, int(buffer), int(row0), rows.numel() // rb, ctypes.c_void_p(rows.data_ptr()), 1, stream), "nesr_band_rows")
+
+    def set_concurrent(self, concurrent: bool):
+        """Hint for kernel selection: forwards of this model's contexts run beside each other on several streams
+        (set automatically when a context replica is created; clear it to time one forward alone)."""
+        lib = _lib.load()
+        for h in ([self._ctx] if self._ctx is not None else []) + list(self._extra.values()):
+            _lib.check(lib.nesr_set_concurrent(h[0], 1 if concurrent else 0), "nesr_set_concurrent")
 
     def preferred_batch(self, device, h, w, max_batch):
         """Tiles of h x w input per forward call that fill the GPU's CUs most evenly (<= max_batch)."""
