@@ -43,6 +43,8 @@ WORKLOADS = {
     "c2": dict(h=512, w=512, scale=2, dtype="f32", tile=0, tile_pad=10, desc="512x512->1024x1024 RealESRGAN_x2plus fp32 single tile"),
     "c2-bf16": dict(h=512, w=512, scale=2, dtype="bf16", tile=0, tile_pad=10, desc="512x512->1024x1024 RealESRGAN_x2plus bf16 single tile"),
     "c3": dict(h=2160, w=3840, scale=2, dtype="bf16", tile=512, tile_pad=10, desc="3840x2160->7680x4320 RealESRGAN_x2plus bf16, tile 512/10"),
+    "c3-stream": dict(h=2160, w=3840, scale=2, dtype="bf16", tile=512, tile_pad=10, independent=True,
+                      desc="3840x2160->7680x4320 RealESRGAN_x2plus bf16, tile 512/10, one independent frame per GPU (a video stream: weak scaling)"),
     "c3-f32": dict(h=2160, w=3840, scale=2, dtype="f32", tile=512, tile_pad=10, desc="3840x2160->7680x4320 RealESRGAN_x2plus fp32, tile 512/10"),
     "c3-exact": dict(h=2160, w=3840, scale=2, dtype="f32", tile=0, tile_pad=10, banded=True,
                      desc="3840x2160->7680x4320 RealESRGAN_x2plus fp32, untiled (tile=0, as nesr/nesr.py:224); N>1: row bands + RCCL apron exchange per RDB"),
@@ -165,7 +167,7 @@ def main():
         from neural_enhanced_super_resolution_amd import banded
         frame = synthetic_frame(wl["h"], wl["w"], seed=0)
         band = torch.from_numpy(banded.scatter_band(frame, rank, world, net.unshuffle)).to(dev)
-    sharded_frame = wl["tile"] > 0 and world > 1
+    sharded_frame = wl["tile"] > 0 and world > 1 and not wl.get("independent")
     if sharded_frame:
         # one frame for the whole job: tiles of upstream's grid sharded over the ranks, overlap rows
         # exchanged point-to-point over RCCL, result gathered on rank 0 (strong scaling)
