@@ -151,6 +151,20 @@ def test_linearity_property_at_full_size(cuda_device):
     assert (lhs - rhs).abs().max().item() < 1e-4
 
 
+def test_linearity_property_at_full_size_f16_pair_form(cuda_device):
+    """The same property for the default f32 form (operands as f16 pairs) at the full C2 layer size, plus
+    homogeneity by a power of two (exact for the pair representation except where a lo half is an f16 subnormal)."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 64, 256, 256, generator=g).to(cuda_device)
+    y = torch.randn(1, 64, 256, 256, generator=g).to(cuda_device)
+    w = torch.randn(32, 64, 3, 3, generator=g) * 0.05
+    b = torch.zeros(32)
+    cx, cy = conv3x3(x, w, b, dtype="f32-split"), conv3x3(y, w, b, dtype="f32-split")
+    lhs = conv3x3(1.5 * x - 0.5 * y, w, b, dtype="f32-split")
+    assert (lhs - (1.5 * cx - 0.5 * cy)).abs().max().item() < 1e-4
+    assert (conv3x3(4.0 * x, w, b, dtype="f32-split") - 4.0 * cx).abs().max().item() < 4e-6 * cx.abs().max().item()
+
+
 @pytest.mark.parametrize("algo,shift", [("f32-direct", 2), ("f32", 2), ("f32-winograd", 4)])
 def test_translation_property_full_net(cuda_device, algo, shift):
     """Away from borders the network commutes with translation: the direct and the f16-pair kernels'
