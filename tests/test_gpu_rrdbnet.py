@@ -189,3 +189,27 @@ def test_split_big_frame_and_batch(cuda_device):
     want = ref(x[1:2])
     assert (got[1:2] - want).abs().max().item() < 2e-5
     assert torch.equal(ours(x[2:3].to(cuda_device)).cpu(), got[2:3])
+
+
+def test_f32_forms_against_an_f64_evaluation(cuda_device):
+    """Ground truth for "f32-class": the 23-block net evaluated in float64 on the CPU.  torch's own f32 CPU path is
+    ~1e-6 away from it; every f32 form of the HIP path must be in that class (the f16-pair form carries 22-23
+    significant bits per operand and drops the lo*lo product), far inside the 1e-3 north-star tolerance."""
+    from neural_enhanced_super_resolution_amd import RRDBNet
+    from neural_enhanced_super_resolution_amd.synth import synthetic_state_dict
+    from oracle.rrdbnet_ref import rrdbnet_forward
+    sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=2, num_block=23)
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        y64 = rrdbnet_forward(x.double(), {k: v.double() for k, v in sd.items()}, scale=2, num_block=23)
+        e_cpu = (rrdbnet_forward(x, sd, scale=2, num_block=23).double() - y64).abs().max().item()
+    errs = {}
+    for algo in ("f32", "f32-winograd", "f32-direct"):
+        net = RRDBNet(3, 3, scale=2, num_block=23, compute_dtype=algo)
+        net.load_state_dict(sd)
+        net.eval().to("cuda:0")
+        errs[algo] = (net(x.to(cuda_device)).cpu().double() - y64).abs().max().item()
+    print("max abs error vs f64: torch CPU f32 %.2e | f16-pair %.2e | winograd %.2e | direct f32 MFMA %.2e"
+          % (e_cpu, errs["f32"], errs["f32-winograd"], errs["f32-direct"]))
+    assert all(e < 1e-5 for e in errs.values()), errs
+    assert errs["f32"] < 5 * max(e_cpu, errs["f32-direct"]), (errs, e_cpu)
