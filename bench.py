@@ -176,8 +176,9 @@ def main():
         band = torch.from_numpy(sharded.scatter_rows(frame, rank, world)).to(dev)
 
     # single-tile workloads: `inflight` independent frames per step, each on its own stream with its own context
-    # replica -- a 512x512 frame's layers are 256-512 workgroups and 4 us of launch floor each, so a second
-    # frame's kernels fill the gaps and the idle half of the LDS / wave slots (tools/probes/concurrent_frames.py)
+    # replica -- a 512x512 frame's layers are one-round launches of 256-512 workgroups (all in their prologue, then
+    # all in their epilogue, 1.3 us between dependent kernels), so a second frame's kernels fill the gaps and the
+    # idle half of the LDS / wave slots (tools/probes/concurrent_frames.py, tools/probes/launch_floor.hip)
     inflight = args.inflight if args.inflight else (2 if (wl["tile"] == 0 and not wl.get("banded")) else 1)
     if wl["tile"] > 0 or wl.get("banded"):
         inflight = 1

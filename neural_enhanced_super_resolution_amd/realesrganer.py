@@ -294,7 +294,7 @@ class RealESRGANer:
         """``[self.enhance(img) for img in imgs]`` with up to `inflight` frames on the GPU at once.
 
         Not part of upstream's API: a frame whose network layers are only a few hundred workgroups (512x512:
-        256-512 per layer, each launch ~4 us of fixed cost) leaves half the GPU idle; a second frame on its own HIP
+        256-512 per layer in one round, all in the same phase) leaves the GPU idle a third of the time; a second frame on its own HIP
         stream and context replica fills it (bench.py's default `value`: 1.19x the one-at-a-time rate).  Frames
         that do not take the fused 8-bit path (tiling, padding, alpha, 16 bit) are processed one at a time.
         The results are identical to enhance()'s."""
