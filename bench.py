@@ -117,7 +117,7 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--inflight", type=int, default=None,
                     help="frames in flight per GPU for the single-tile workloads (each on its own HIP stream and context "
-                         "replica); default 2 for c2 / c2-bf16, 1 otherwise")
+                         "replica); default 4 for c2 / c2-bf16 (2: -5 %, 1: -20 %, 6-8: no more), 1 otherwise")
     ap.add_argument("--f32-algo", default=None, choices=["split", "winograd", "direct"],
                     help="conv algorithm of the fp32 workloads (default split: f16 hi+lo operand pairs)")
     args = ap.parse_args()
@@ -179,7 +179,7 @@ def main():
     # replica -- a 512x512 frame's layers are one-round launches of 256-512 workgroups (all in their prologue, then
     # all in their epilogue, 1.3 us between dependent kernels), so a second frame's kernels fill the gaps and the
     # idle half of the LDS / wave slots (tools/probes/concurrent_frames.py, tools/probes/launch_floor.hip)
-    inflight = args.inflight if args.inflight else (2 if (wl["tile"] == 0 and not wl.get("banded")) else 1)
+    inflight = args.inflight if args.inflight else (4 if (wl["tile"] == 0 and not wl.get("banded")) else 1)
     if wl["tile"] > 0 or wl.get("banded"):
         inflight = 1
     xs, streams = [x], [torch.cuda.current_stream(dev)]
