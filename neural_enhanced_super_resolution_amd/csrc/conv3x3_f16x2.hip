@@ -124,7 +124,7 @@ __device__ __forceinline__ f32x4 ld4_split(const uint16_t* p) {
 }
 
 #ifndef NESR_ABL
-#define NESR_ABL 0   // timing ablations: 1 empty kernel, 2 stop after the prologue, 4 no epilogue, 8 no MFMA, 16 no K-loop DMA, 64 cycle stamps
+#define NESR_ABL 0   // timing ablations: 1 empty kernel, 2 stop after the prologue, 4 no epilogue, 8 no MFMA, 16 no K-loop DMA, 64 cycle stamps, 128 MFMA-shape substitution (32-shape build), 512 no per-chunk barrier
 #endif
 #if NESR_ABL & 64
 __device__ unsigned long long g_stamps[256];
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
         // this wave's DMAs of chunk c (issued during chunk c-1) have landed; after the barrier, everybody's
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         STAMP(8 + 4 * c);
-        __builtin_amdgcn_s_barrier();
+        if (!(NESR_ABL & 512)) __builtin_amdgcn_s_barrier();   // 512: timing only (races)
         asm volatile("" ::: "memory");
         STAMP(9 + 4 * c);
         // the next chunk's DMAs go out first (beside the MFMAs each costs 150+ cycles of issue instead of ~85:
