@@ -187,6 +187,8 @@ def main():
         up.pre_process(np.ascontiguousarray(synthetic_frame(wl["h"], wl["w"], seed=1000 * i + rank)[:, :, ::-1].astype(np.float32) / 255.0))
         xs.append(up.img)
         streams.append(torch.cuda.Stream(dev))
+    for st in streams[1:]:
+        st.wait_stream(streams[0])      # xs[i] were produced on the main stream
 
     def step():
         if inflight > 1:

@@ -767,14 +767,24 @@ int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, in
         pack_weights_f32(w_host, Cout, Cin, cin_p, cout_p, reinterpret_cast<float*>(hw.data()));
     std::vector<float> hb(cout_p, 0.f);
     std::memcpy(hb.data(), b_host, (size_t)Cout * 4);
+    // device scratch of this one call; freed on every return path
+    struct Scratch {
+        std::vector<void*> ptrs;
+        ~Scratch() { for (void* p : ptrs) (void)hipFree(p); }
+        hipError_t take(void** p, size_t bytes) {
+            const hipError_t e = hipMalloc(p, bytes);
+            if (e == hipSuccess) ptrs.push_back(*p);
+            return e;
+        }
+    } scratch;
     char *d_w = nullptr, *d_in = nullptr, *d_out = nullptr, *d_zero = nullptr;
     float* d_b = nullptr;
     const size_t in_bytes = (size_t)N * H * W * cin_p * es, out_bytes = (size_t)N * ho * wo * cout_p * es;
-    HIP_TRY(hipMalloc((void**)&d_w, hw.size()));
-    HIP_TRY(hipMalloc((void**)&d_b, hb.size() * 4));
-    HIP_TRY(hipMalloc((void**)&d_in, in_bytes));
-    HIP_TRY(hipMalloc((void**)&d_out, out_bytes));
-    HIP_TRY(hipMalloc((void**)&d_zero, 256));
+    HIP_TRY(scratch.take((void**)&d_w, hw.size()));
+    HIP_TRY(scratch.take((void**)&d_b, hb.size() * 4));
+    HIP_TRY(scratch.take((void**)&d_in, in_bytes));
+    HIP_TRY(scratch.take((void**)&d_out, out_bytes));
+    HIP_TRY(scratch.take((void**)&d_zero, 256));
     HIP_TRY(hipMemset(d_zero, 0, 256));
     HIP_TRY(hipMemcpy(d_w, hw.data(), hw.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
@@ -794,7 +804,6 @@ int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, in
     HIP_TRY(sp ? launch_conv3x3_f16x2(a, s) : bf ? launch_conv3x3_bf16(a, s) : (wino ? launch_conv3x3_wino_f32(a, s) : launch_conv3x3_f32(a, s)));
     HIP_TRY(launch_nhwc_to_nchw(d_out, kind, mo, N, Cout, ho, wo, static_cast<float*>(y_dev), s));
     HIP_TRY(hipStreamSynchronize(s));
-    (void)hipFree(d_w); (void)hipFree(d_b); (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(d_zero);
     return NESR_OK;
 }
 

@@ -303,6 +303,9 @@ class RealESRGANer:
         if inflight <= 1 or not imgs or not all(self._fused_u8_ok(i) for i in imgs):
             return [self.enhance(i) for i in imgs]
         streams = [torch.cuda.Stream(self.device) for _ in range(inflight)]
+        caller = torch.cuda.current_stream(self.device)
+        for st in streams:
+            st.wait_stream(caller)     # the context workspaces (slot 0 is the caller's own) may still be in use there
         results, pending = [None] * len(imgs), []
 
         def finish(entry):
@@ -324,6 +327,8 @@ class RealESRGANer:
             pending.append((i, host, ev))
         for entry in pending:
             finish(entry)
+        for st in streams:
+            caller.wait_stream(st)
         return results
 
     @torch.no_grad()

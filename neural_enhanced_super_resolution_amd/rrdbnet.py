@@ -203,21 +203,10 @@ class RRDBNet(nn.Module):
                     _lib.check(lib.nesr_set_concurrent(h[0], 1), "nesr_set_concurrent")
             return self._extra[slot][0]
         if self._ctx is None:
-            handle = ctypes.c_void_p()
-            unshuffle = {2: 2, 1: 4}.get(self.scale, 0)
-            _lib.check(lib.nesr_create(ctypes.byref(handle), index, conv_first_in_ch(self.num_in_ch, self.scale),
-                                       unshuffle, self.num_feat, self.num_block, self.num_grow_ch, self.num_out_ch, code),
-                       "nesr_create")
-            self._ctx = (handle, index, code)
+            self._ctx = (self._create(index, code), index, code)
             self._dirty = True
         if self._dirty:
-            handle = self._ctx[0]
-            for key, t in self.state_dict().items():
-                arr = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
-                shape = (ctypes.c_int64 * arr.dim())(*arr.shape)
-                _lib.check(lib.nesr_load_weight(handle, key.encode(), ctypes.c_void_p(arr.data_ptr()), shape, arr.dim()),
-                           f"nesr_load_weight({key})")
-            _lib.check(lib.nesr_finalize_weights(handle), "nesr_finalize_weights")
+            self._upload(self._ctx[0])
             self._dirty = False
         return self._ctx[0]
 
@@ -357,6 +346,8 @@ class RRDBNet(nn.Module):
         ctx, dev, stream = self._band_call()
         lib = _lib.load()
         rb = int(lib.nesr_band_row_bytes(ctx))
+        if rb == 0:
+            raise RuntimeError("band_set_rows: no banded evaluation is active (band_begin has not run, or a whole-frame forward reused the workspace)")
         rows = rows.to(dev).contiguous()
         if rows.dtype != torch.uint8 or rows.numel() % rb:
             raise ValueError("rows must be the uint8 tensor band_rows() returned on the sending rank")
