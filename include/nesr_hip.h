@@ -32,9 +32,13 @@ typedef struct nesr_ctx nesr_ctx;
 /* NESR_DTYPE_F32_WINOGRAD: f32 storage and f32 matrix-core arithmetic, the feature-map 3x3 convs
  * evaluated by Winograd F(2x2,3x3) (2.25x less matrix work; a few ulps per layer away from the
  * direct form, far inside the 1e-3 output tolerance). */
-/* NESR_DTYPE_F32_SPLIT: f32 in, f32 out, f32 accumulation; every conv operand is carried as an exact-sum
- * pair of halves (x = hi + lo) and each product is three f16 MFMAs (hi*hi + hi*lo + lo*hi), see
- * conv3x3_f16x2.hip.  Whole-network max abs error vs an f64 evaluation 3e-6 (plain f32: 1e-6). */
+/* NESR_DTYPE_F32_SPLIT: f32 in, f32 out, f32 accumulation; every conv operand is carried as a pair of halves,
+ * x = hi + lo * 2^-11 (hi = f16(x), lo = f16((x - hi) * 2^11)), and each product is three f16 MFMAs
+ * (hi*hi + hi*lo + lo*hi), see conv3x3_f16x2.hip.  The pair holds 22 significant bits for 6.1e-5 <= |x| <= 65504
+ * and an absolute 2^-35 below; a value outside +-65504 or a non-finite one does NOT fit: nesr_finalize_weights
+ * rejects such a weight (NESR_ERR_RANGE), and such an input or activation raises the context's sticky range flag --
+ * the float output of that forward is then NaN and nesr_check_range / nesr_check_status return NESR_ERR_RANGE.
+ * Whole-network max abs error vs an f64 evaluation 3e-6 on the bench weights (plain f32: 1e-6). */
 enum { NESR_DTYPE_F32 = 0, NESR_DTYPE_BF16 = 1, NESR_DTYPE_F32_WINOGRAD = 2, NESR_DTYPE_F32_SPLIT = 3 };
 enum { NESR_ROUND_TRUNC = 0, NESR_ROUND_NEAREST = 1 };
 
@@ -43,7 +47,8 @@ enum {
     NESR_ERR_ARG = -1,      /* bad argument / unsupported shape */
     NESR_ERR_HIP = -2,      /* a HIP runtime call failed */
     NESR_ERR_STATE = -3,    /* weights missing / not finalized */
-    NESR_ERR_NOMEM = -4
+    NESR_ERR_NOMEM = -4,
+    NESR_ERR_RANGE = -5     /* f16-pair fp32 form: a weight, input or activation was non-finite or beyond +-65504 */
 };
 
 /*
@@ -145,8 +150,16 @@ int nesr_set_kernel_timing(nesr_ctx* ctx, int enable);
 int nesr_kernel_time_ms(nesr_ctx* ctx, double* total_ms, int64_t* launches, double* flops);
 
 /* Waits for the device and reports deferred failures of asynchronous work (the persistent trunk
- * kernel bounds every inter-workgroup wait and sets an abort word instead of hanging). */
+ * kernel bounds every inter-workgroup wait and sets an abort word instead of hanging; the f16-pair
+ * form's range flag, see nesr_check_range). */
 int nesr_check_status(nesr_ctx* ctx);
+
+/* Range check of the forwards enqueued so far on `hip_stream` (NESR_DTYPE_F32_SPLIT; NESR_OK at once for the
+ * other dtypes): waits for that stream only, returns NESR_ERR_RANGE if an input or activation did not fit the
+ * (hi, lo) pair, and clears the flag.  Where the reference would hand back NaN/Inf pixels
+ * (`model(img)` on diverged data, nesr/nesr.py:891) this path hands back NaN (float output) plus this error; the
+ * Python wrappers call it after every device-to-host copy. */
+int nesr_check_range(nesr_ctx* ctx, void* hip_stream);
 
 void nesr_destroy(nesr_ctx* ctx);
 

@@ -38,6 +38,7 @@ SIGNATURES = {
     "nesr_set_kernel_timing": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "nesr_kernel_time_ms": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_double)]),
     "nesr_check_status": (_c.c_int, [_c.c_void_p]),
+    "nesr_check_range": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "nesr_destroy": (None, [_c.c_void_p]),
     "nesr_conv3x3": (_c.c_int, [_c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
                                 _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
@@ -49,8 +50,16 @@ _lib = None
 _lock = threading.Lock()
 
 
+ERR_RANGE = -5
+
+
 class NesrHipError(RuntimeError):
     """A libnesr_hip.so call returned a negative status."""
+
+
+class NesrRangeError(NesrHipError, FloatingPointError):
+    """NESR_ERR_RANGE: the f16-pair fp32 form met a weight, input or activation that is non-finite or beyond
+    +-65504 (the reference would carry it in float32; here it is an error, never a saturated image)."""
 
 
 def load():
@@ -77,4 +86,5 @@ def load():
 def check(rc, what):
     if rc != 0:
         msg = load().nesr_last_error()
-        raise NesrHipError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")
+        cls = NesrRangeError if rc == ERR_RANGE else NesrHipError
+        raise cls(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

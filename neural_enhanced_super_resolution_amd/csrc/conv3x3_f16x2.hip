@@ -1,25 +1,32 @@
 // f32 3x3 convolution on the f16 matrix cores: every f32 operand travels as an exact-sum pair of
-// halves (x = hi + lo, hi = f16(x), lo = f16(x - hi): 22-23 significant bits, f16 subnormals
-// included) and the product is accumulated in f32 from three MFMAs
+// halves, x = hi + lo * 2^-11 with hi = f16(x), lo = f16((x - hi) * 2^11), and the product is
+// accumulated in f32 from three MFMAs
 //
-//     w*x  ~=  w_hi*x_hi + w_hi*x_lo + w_lo*x_hi                (dropped: w_lo*x_lo ~ 2^-22 |w x|)
+//     w*x  ~=  w_hi*x_hi + 2^-11 (w_hi*x_lo + w_lo*x_hi)        (dropped: w_lo*x_lo ~ 2^-22 |w x|)
+//
+// The two cross terms have their own f32 accumulator and are scaled once in the epilogue.  Precision of
+// the pair: hi carries 11 significant bits and lo (kept normal by the 2^11 scale) the next 11, so
+// |x - (hi + lo 2^-11)| <= 2^-22 |x| for 6.1e-5 <= |x| <= 65504; below 6.1e-5 hi is an f16 subnormal
+// (absolute step 2^-24) and the scaled lo resolves the rest to an absolute 2^-35.  Range: |x| > 65504
+// or a non-finite x does not fit; such a value is clamped AND reported -- a sticky device flag
+// (ConvArgs::status) that nesr_check_status / nesr_check_range turn into NESR_ERR_RANGE and that makes
+// conv_last write NaN instead of a saturated image (a diverged network gives NaN in the reference too).
 //
 // v_mfma_f32_32x32x16_f16 runs at 16x the rate of the f32 MFMA, so three of them cost 3/16 of the
 // direct f32 kernel's matrix time and 27/64 of the Winograd kernel's.  Measured on the 23-block
 // network against an f64 evaluation of the same weights (tools/probes/split_accuracy.py): max abs
 // error 3.1e-6 for this scheme, 1.2e-6 for plain f32 (torch CPU), i.e. the same class of error
-// as the Winograd kernel -- 300x inside the 1e-3 tolerance.  The MFMA honours f16 subnormal inputs
-// on gfx950 (tools/probes/mfma_f16_denorm.hip), so lo needs no scaling; |x| is clamped to 65504.
+// as the Winograd kernel -- 300x inside the 1e-3 tolerance.  (The MFMA honours f16 subnormal inputs on
+// gfx950, tools/probes/mfma_f16_denorm.hip: hi needs no special case.)
 //
 // Activations live pre-split in HBM, channel-blocked like the bf16 path: per 16-channel K-chunk a
-// pixel owns 64 bytes = [16 hi halves | 16 lo halves] (Map: pix = 32, chunk = pixels * 32, in
+// pixel owns 64 bytes = [16 hi halves | 16 scaled-lo halves] (Map: pix = 32, chunk = pixels * 32, in
 // 2-byte units); the producing kernel's epilogue splits once, the consumers feed LDS by LDS-DMA
 // without touching a VGPR.  Same 4 bytes per value as f32 storage.
 //
-//   workgroup : 4 waves, output tile 8 or 16 rows x 32 cols x 32 output channels; wave w owns rows
-//               RW w .. RW w + RW - 1 (the MFMA's 32 columns = 32 pixels of a row).  Layers with 64
-//               output channels run two workgroups per tile (adjacent in the launch order).
-//               (-DNESR_SPLIT_WAVES=8 builds the 8-wave form of the same tiles: measured 3-5 % slower.)
+//   workgroup : 4 MFMA waves (+ 4 DMA-only waves when a CU gets one workgroup), output tile 8 rows x 32 cols
+//               x 32 output channels; wave w owns rows 2w, 2w+1.  Layers with 64 output channels run two
+//               workgroups per tile (adjacent in the launch order).
 //   K loop    : 16-channel chunks; input halo tile [(rows+2) x 34 pixels][64 B] and weight slab
 //               [9 taps][hi|lo][k half][32 couts][16 B] by LDS-DMA into 2-slot rings, counted
 //               vmcnt waits + one barrier per chunk (as conv3x3_bf16.hip).
@@ -43,17 +50,11 @@ typedef __attribute__((address_space(3))) char lds_char;
 namespace {
 
 constexpr int TW = 32, PW = TW + 2;
-#ifndef NESR_SPLIT_WAVES
-#define NESR_SPLIT_WAVES 4
-#endif
-#ifndef NESR_SPLIT_SHAPE
-#define NESR_SPLIT_SHAPE 16   // MFMA shape: 16 = v_mfma_f32_16x16x32_f16 (K = two (tap, product) units), 32 = 32x32x16
-#endif
-constexpr int WAVES = NESR_SPLIT_WAVES;          // MFMA waves per workgroup
-constexpr int RW_S = 8 / WAVES, RW_L = 16 / WAVES;   // rows per wave of the 8x32 and the 16x32 tile
+constexpr int WAVES = 4;   // MFMA waves per workgroup
+constexpr int RW = 2;      // rows per MFMA wave: output tile 8 rows x 32 cols x 32 output channels
 
 // DMAW = extra waves that only issue the LDS-DMAs (0: the MFMA waves issue them themselves)
-template <int RW, int DMAW>
+template <int DMAW>
 struct Geo {
     static constexpr int LAUNCH_THREADS = 64 * (WAVES + DMAW);
     static constexpr int THREADS = 64 * (DMAW ? DMAW : WAVES);   // lanes that share one DMA round
@@ -64,7 +65,9 @@ struct Geo {
     static constexpr int IN_ROUNDS = (IN_ITEMS + THREADS - 1) / THREADS;
     static constexpr int IN_BYTES = IN_ITEMS * 16;
 };
-constexpr int W_ITEMS1 = 9 * 2 * 2 * 32;   // 16-byte items of one 32-cout weight slab (per K-chunk)
+constexpr int W_ITEMS = 9 * 2 * 2 * 32;   // 16-byte items of one 32-cout weight slab (per K-chunk)
+constexpr int W_BYTES = W_ITEMS * 16;
+constexpr int ISLOTS = 2;                 // two-slot rings: every wait is vmcnt(0)
 
 // LDS-DMA from inline asm (see conv3x3_bf16.hip): not counted by hipcc, waited for by hand.
 __device__ __forceinline__ void glds16_asm(const char* gsrc, unsigned lds_dst) {
@@ -103,15 +106,19 @@ __device__ __forceinline__ void store16(uint16_t* p, uint4 v) {
 #endif
 }
 
-// x -> (hi, lo) halves of 4 values
-__device__ __forceinline__ void split4(f32x4 v, uint2& hi, uint2& lo) {
+constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;   // lo is stored as f16((x - hi) * 2^11)
+constexpr float F16_MAX = 65504.f;
+
+// x -> (hi, scaled lo) halves of 4 values; `bad` collects "does not fit the pair" (|x| > 65504, NaN, Inf)
+__device__ __forceinline__ void split4(f32x4 v, uint2& hi, uint2& lo, bool& bad) {
     f16x4 h, l;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float x = fminf(fmaxf(v[q], -65504.f), 65504.f);
+        bad |= !(__builtin_fabsf(v[q]) <= F16_MAX);
+        const float x = fminf(fmaxf(v[q], -F16_MAX), F16_MAX);
         const _Float16 hq = (_Float16)x;
         h[q] = hq;
-        l[q] = (_Float16)(x - (float)hq);
+        l[q] = (_Float16)((x - (float)hq) * LO_SCALE);
     }
     hi = __builtin_bit_cast(uint2, h);
     lo = __builtin_bit_cast(uint2, l);
@@ -120,11 +127,12 @@ __device__ __forceinline__ void split4(f32x4 v, uint2& hi, uint2& lo) {
 __device__ __forceinline__ f32x4 ld4_split(const uint16_t* p) {
     const f16x4 h = *reinterpret_cast<const f16x4*>(p);
     const f16x4 l = *reinterpret_cast<const f16x4*>(p + 16);
-    return f32x4{(float)h[0] + (float)l[0], (float)h[1] + (float)l[1], (float)h[2] + (float)l[2], (float)h[3] + (float)l[3]};
+    return f32x4{fmaf((float)l[0], LO_INV, (float)h[0]), fmaf((float)l[1], LO_INV, (float)h[1]),
+                 fmaf((float)l[2], LO_INV, (float)h[2]), fmaf((float)l[3], LO_INV, (float)h[3])};
 }
 
 #ifndef NESR_ABL
-#define NESR_ABL 0   // timing ablations: 1 empty kernel, 2 stop after the prologue, 4 no epilogue, 8 no MFMA, 16 no K-loop DMA, 64 cycle stamps, 128 MFMA-shape substitution (32-shape build), 512 no per-chunk barrier
+#define NESR_ABL 0   // timing ablations: 1 empty kernel, 2 stop after the prologue, 4 no epilogue, 8 no MFMA, 16 no K-loop DMA, 64 cycle stamps, 512 no per-chunk barrier
 #endif
 #if NESR_ABL & 64
 __device__ unsigned long long g_stamps[256];
@@ -133,31 +141,14 @@ __device__ unsigned long long g_stamps[256];
 #else
 #define STAMP(i) do { } while (0)
 #endif
-// timing experiment (-DNESR_ABL=128, values WRONG): each 32x32x16 MFMA replaced by two 16x16x32 MFMAs of the same
-// total FLOPs on two quarters of the accumulator -- does the chip hold a higher clock on that shape?
-__device__ __forceinline__ f32x16 MFMA32(f16x8 a, f16x8 b, f32x16 c, int, int, int) {
-#if NESR_ABL & 128
-    f32x4 lo = __builtin_shufflevector(c, c, 0, 1, 2, 3), hi = __builtin_shufflevector(c, c, 8, 9, 10, 11);
-    lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, lo, 0, 0, 0);
-    hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, hi, 0, 0, 0);
-    c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3];
-    c[8] = hi[0]; c[9] = hi[1]; c[10] = hi[2]; c[11] = hi[3];
-    return c;
-#else
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-#endif
-}
 
-// NT = 32-channel output groups per workgroup (2: a 64-channel layer stages its input once)
-template <int RW, int ISLOTS, int DMAW, int NACC, int NT>
-__global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES + DMAW) / 4 : (WAVES / 4) * (RW == RW_S ? 2 : 1)) void conv3x3_f16x2_kernel(ConvArgs a) {
+template <int DMAW>
+__global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : 2) void conv3x3_f16x2_kernel(ConvArgs a) {
     if (NESR_ABL & 1) return;
-    typedef Geo<RW, DMAW> G;
+    typedef Geo<DMAW> G;
     constexpr int THREADS = G::THREADS, TH = G::TH;
     constexpr int IN_ITEMS = G::IN_ITEMS, IN_ROUNDS = G::IN_ROUNDS, IN_BYTES = G::IN_BYTES;
-    constexpr int W_ITEMS = W_ITEMS1 * NT;   // the NT slabs of a chunk are consecutive in the packed weights
     constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
-    constexpr int W_BYTES = W_ITEMS * 16;
     constexpr int WRING = ISLOTS * IN_BYTES;   // LDS: [input ring][weight ring: 2 x W_BYTES]
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -172,10 +163,8 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
 #endif
     STAMP(0);
 
-    static_assert(ISLOTS == 2, "two-slot rings: every wait is vmcnt(0)");
-    constexpr bool S16 = NESR_SPLIT_SHAPE == 16 && NT == 1;
     // ---- XCD-aware work index (bijective for any count); the cout groups of one tile are neighbours
-    const int CG = a.coutp / (32 * NT);
+    const int CG = a.coutp / 32;
     const int tiles_x = (a.w_ + TW - 1) / TW;
     const int tiles_y = (a.h + TH - 1) / TH;
     const int total = tiles_x * tiles_y * a.n * CG;
@@ -193,7 +182,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
     const int y0 = ty * TH, x0 = tx * TW;
 
     // ---- LDS-DMA plan.  LDS item k of an input slot = padded pixel k>>2, physical slot k&3; it holds
-    // logical slot (k&3) ^ ((padded column >> 2) & 3) of that pixel's 64 bytes.  Item k = tid + THREADS*i
+    // logical slot (k&3) ^ (bit 2 of the padded column << 1) of that pixel's 64 bytes.  Item k = tid + THREADS*i
     // belongs to this lane in round i; its source is (scalar base of image n and chunk c) + voff[i].
     // Out-of-image items (the conv's zero padding) are the same for every chunk: they are zeroed once in
     // every ring slot and left out of the DMAs (EXEC-masked lanes do not write).
@@ -206,14 +195,14 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
     const long long w_cstride = (long long)CG * W_BYTES;
     // DMA round j of chunk c: rounds [0, W_ROUNDS) move the weight slab, the rest the input tile
     constexpr int NDMA = W_ROUNDS + IN_ROUNDS;
-    auto dma_round = [&](int c, int wslot, int islot_, int j) {   // j is a compile-time constant at every call site
+    auto dma_round = [&](int c, int slot, int j) {   // j is a compile-time constant at every call site
         if (j < W_ROUNDS) {
             const int k = tid + THREADS * j;
-            const unsigned dst = lds_base + WRING + wslot * W_BYTES + j * (THREADS * 16) + wave * 1024;
+            const unsigned dst = lds_base + WRING + slot * W_BYTES + j * (THREADS * 16) + wave * 1024;
             if (k < W_ITEMS) glds16_s(wbase + (long long)c * w_cstride, (unsigned)k * 16u, __builtin_amdgcn_readfirstlane(dst));
         } else if (j < NDMA) {
             const int i = j - W_ROUNDS;
-            const unsigned dst = lds_base + islot_ * IN_BYTES + i * (THREADS * 16) + wave * 1024;
+            const unsigned dst = lds_base + slot * IN_BYTES + i * (THREADS * 16) + wave * 1024;
             if ((okmask >> i) & 1u) glds16_s(in_img + (long long)c * in_cstride, voff[i], __builtin_amdgcn_readfirstlane(dst));
         }
     };
@@ -221,20 +210,20 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
     // soon as its offsets exist, so the first bytes are under way while the rest is still being computed
     if (is_dma) {
 #pragma unroll
-        for (int j = 0; j < W_ROUNDS; ++j) dma_round(0, 0, 0, j);
+        for (int j = 0; j < W_ROUNDS; ++j) dma_round(0, 0, j);
         int p = tid >> 2;
         int py = p / PW, px = p - py * PW;
         const int sl = tid & 3;
 #pragma unroll
         for (int i = 0; i < IN_ROUNDS; ++i) {
             const int k = tid + THREADS * i;
-            const int sg = S16 ? sl ^ (((px >> 2) & 1) << 1) : sl ^ ((px >> 2) & 3);
+            const int sg = sl ^ (((px >> 2) & 1) << 1);
             const int Y = y0 - 1 + py, X = x0 - 1 + px;
             const bool has = k < IN_ITEMS;
             const bool ok = has && Y >= 0 && Y < a.h && X >= 0 && X < a.w_;
             voff[i] = ((unsigned)(Y >> a.up) * (unsigned)a.in_w + (unsigned)(X >> a.up)) * 64u + sg * 16;
             okmask |= ok ? (1u << i) : 0u;
-            dma_round(0, 0, 0, W_ROUNDS + i);
+            dma_round(0, 0, W_ROUNDS + i);
             if (has && !ok) {
 #pragma unroll
                 for (int sl2 = 0; sl2 < ISLOTS; ++sl2) *reinterpret_cast<f32x4*>(smem + sl2 * IN_BYTES + k * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -246,26 +235,20 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
     }
     STAMP(6);
 
-    // ---- per-lane operand coordinates
-    const int m = lane & 31, hh = lane >> 5;
-    // byte offset inside an input slot of this lane's hi fragment for horizontal tap dx, row 0 of the
-    // wave's RW + 2; the lo fragment is the same offset ^ 32
-    int p_off[3];
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) p_off[dx] = ((RW * wave) * PW + m + dx) * 64 + ((hh ^ (((m + dx) >> 2) & 3)) << 4);
-    const int w_off = hh * 32 + m;   // item index inside a weight slab: ((tap*2 + plane)*2 + hh)*32 + cout
     const bool active = is_cmp && (y0 + RW * wave) < a.h;
 
-    // ---- 16x16x32 form.  The MFMA's K = 32 is two units of 16 channels: lanes 0-31 (k-groups g = 0,1 = channel
-    // halves) feed unit 0, lanes 32-63 unit 1, and a unit is one (tap, plane) choice -- just another per-lane LDS
-    // address.  Steps 0-2 pair the taps (dy 0 | dy 1) of column dx = step, step 3 pairs (2,0) | (2,1); with
-    // WH/WL = [w(tap a) | w(tap b)] and XH/XL = [x(tap a) | x(tap b)] a step is WH*XH + WH*XL + WL*XH.  Step 4 is
-    // tap (2,2) alone: [w_hi | w_hi] * [x_hi | x_lo] and [w_lo | 0] * [x_hi | x_hi].  14 MFMAs per 16x16 tile and
-    // chunk instead of 13.5; the chip holds a ~20 % higher clock on this shape (tools/probes/mfma_shape.hip).
-    // Tiles of a wave: rows r, pixel halves nh (16 px), cout halves mt (16 couts).  LDS slot swizzle for this lane
-    // order: physical slot = slot ^ (bit 2 of the padded column << 1) (conflict-free for the b128 lane groups).
+    // ---- operands.  The MFMA (v_mfma_f32_16x16x32_f16) has K = 32 = two units of 16 channels: lanes 0-31
+    // (k-groups g = 0,1 = channel halves) feed unit 0, lanes 32-63 unit 1, and a unit is one (tap, plane)
+    // choice -- just another per-lane LDS address.  Steps 0-2 pair the taps (dy 0 | dy 1) of column dx = step,
+    // step 3 pairs (2,0) | (2,1); with WH/WL = [w(tap a) | w(tap b)] and XH/XL = [x(tap a) | x(tap b)] a step is
+    // main += WH*XH, cross += WH*XL + WL*XH.  Step 4 is tap (2,2) alone: main += [w_hi | 0] * [x_hi | .] and
+    // cross += [w_hi | w_lo] * [x_lo | x_hi], i.e. both cross terms in one MFMA.  14 MFMAs per 16x16 tile and
+    // chunk instead of 13.5; the chip holds a ~20 % higher clock on this shape than on 32x32x16
+    // (tools/probes/mfma_shape.hip).  Tiles of a wave: rows r, pixel halves nh (16 px), cout halves mt
+    // (16 couts).  LDS slot swizzle for this lane order: physical slot = slot ^ (bit 2 of the padded column << 1)
+    // (conflict-free for the ds_read_b128 lane groups).
     const int j16 = lane & 15, g4 = lane >> 4, un = g4 >> 1, kh = g4 & 1;
-    int b16[5][2], a16[5], b16x[2];
+    int b16[5][2], a16[5];
 #pragma unroll
     for (int st_ = 0; st_ < 5; ++st_) {
         const int dy = st_ < 3 ? un : 2;
@@ -277,9 +260,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
         }
         a16[st_] = ((((dy * 3 + dx) * 2) * 2 + kh) * 32 + j16) * 16;
     }
-    b16x[0] = b16[4][0] ^ (un << 5);   // [x_hi | x_lo] of the last tap
-    b16x[1] = b16[4][1] ^ (un << 5);
-    f32x4 acc16[RW][2][2][NACC];       // [row][pixel half][cout half][main | cross]
+    f32x4 acc16[RW][2][2][2];       // [row][pixel half][cout half][main | cross]
 #pragma unroll
     for (int r = 0; r < RW; ++r)
 #pragma unroll
@@ -287,31 +268,11 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int q = 0; q < NACC; ++q) acc16[r][nh][mt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int q = 0; q < 2; ++q) acc16[r][nh][mt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     // this lane's 8 output channels after the epilogue's permlane16 exchange, and their bias (fetched now: the
     // latency hides under the K loop)
     const int cb16 = 32 * cg + (g4 & 1) * 16 + (g4 >> 1) * 8;
     const f32x4 bz0 = *reinterpret_cast<const f32x4*>(a.bias + cb16), bz1 = *reinterpret_cast<const f32x4*>(a.bias + cb16 + 4);
-
-    // accumulators.  NACC == 2: [row][0] takes w_hi*x_hi, [row][1] the two cross terms (summed in the
-    // epilogue): consecutive MFMAs never wait on each other's result, and the small terms add up among
-    // themselves.  NACC == 1 (4 rows per wave: the rows alone keep dependent MFMAs apart): one per row.
-    f32x16 acc[RW][NT][NACC];
-#pragma unroll
-    for (int r = 0; r < RW; ++r)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int q = 0; q < NACC; ++q)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[r][t][q][e] = 0.f;
-    constexpr int XA = NACC - 1;   // accumulator of the cross terms
-    // bias now, so that its latency hides under the K loop
-    f32x4 bs[NT][4];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bs[t][g] = *reinterpret_cast<const f32x4*>(a.bias + 32 * (cg * NT + t) + 8 * g + 4 * hh);
 
     const int nchunks = a.cin / 16;
     STAMP(7);
@@ -333,10 +294,10 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
         // measured, in-kernel stamps)
         if (is_dma && c + 1 < nchunks && !(NESR_ABL & 16)) {
 #pragma unroll
-            for (int j = 0; j < NDMA; ++j) dma_round(c + 1, (c + 1) & 1, (c + 1) & 1, j);
+            for (int j = 0; j < NDMA; ++j) dma_round(c + 1, (c + 1) & 1, j);
         }
         STAMP(10 + 4 * c);
-        if (active && S16) {
+        if (active) {
             const char* st = smem + (c & 1) * IN_BYTES;
             const char* swb = smem + WRING + (c & 1) * W_BYTES;
             f32x4 Af[2][2][2];        // [buffer][cout half][variant]
@@ -344,17 +305,22 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
             auto load_step = [&](int s_, int buf) {   // s_ is a compile-time constant at every call site
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
-                    Af[buf][mt][0] = *reinterpret_cast<const f32x4*>(swb + a16[s_] + mt * 256);
-                    f32x4 lo = *reinterpret_cast<const f32x4*>(swb + a16[s_] + mt * 256 + 1024);
-                    if (s_ == 4 && un) lo = f32x4{0.f, 0.f, 0.f, 0.f};    // [w_lo | 0]
-                    Af[buf][mt][1] = lo;
+                    if (s_ < 4) {
+                        Af[buf][mt][0] = *reinterpret_cast<const f32x4*>(swb + a16[s_] + mt * 256);          // WH
+                        Af[buf][mt][1] = *reinterpret_cast<const f32x4*>(swb + a16[s_] + mt * 256 + 1024);   // WL
+                    } else {
+                        f32x4 hi = *reinterpret_cast<const f32x4*>(swb + a16[4] + mt * 256);
+                        Af[buf][mt][1] = *reinterpret_cast<const f32x4*>(swb + a16[4] + mt * 256 + un * 1024);   // [w_hi | w_lo]
+                        if (un) hi = f32x4{0.f, 0.f, 0.f, 0.f};
+                        Af[buf][mt][0] = hi;                                                                      // [w_hi | 0]
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < RW; ++r)
 #pragma unroll
                     for (int nh = 0; nh < 2; ++nh) {
-                        const int o0 = s_ == 4 ? b16x[nh] : b16[s_][nh];            // XH, or [x_hi | x_lo]
-                        const int o1 = s_ == 4 ? b16[4][nh] : (b16[s_][nh] ^ 32);   // XL, or [x_hi | x_hi]
+                        const int o0 = b16[s_][nh];                                             // XH; last tap: [x_hi | x_hi]
+                        const int o1 = s_ == 4 ? (b16[4][nh] ^ ((un ^ 1) << 5)) : (b16[s_][nh] ^ 32);   // XL; last tap: [x_lo | x_hi]
                         Bf[buf][r][nh][0] = *reinterpret_cast<const f32x4*>(st + o0 + r * (PW * 64));
                         Bf[buf][r][nh][1] = *reinterpret_cast<const f32x4*>(st + o1 + r * (PW * 64));
                     }
@@ -378,12 +344,12 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
                         for (int nh = 0; nh < 2; ++nh) {
                             const f16x8 x0_ = __builtin_bit_cast(f16x8, Bf[buf][r][nh][0]), x1_ = __builtin_bit_cast(f16x8, Bf[buf][r][nh][1]);
                             if (s_ < 4) {
-                                acc16[r][nh][mt][XA] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x1_, acc16[r][nh][mt][XA], 0, 0, 0);
+                                acc16[r][nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x1_, acc16[r][nh][mt][1], 0, 0, 0);
                                 acc16[r][nh][mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x0_, acc16[r][nh][mt][0], 0, 0, 0);
-                                acc16[r][nh][mt][XA] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x0_, acc16[r][nh][mt][XA], 0, 0, 0);
+                                acc16[r][nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x0_, acc16[r][nh][mt][1], 0, 0, 0);
                             } else {
                                 acc16[r][nh][mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x0_, acc16[r][nh][mt][0], 0, 0, 0);
-                                acc16[r][nh][mt][XA] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1_, acc16[r][nh][mt][XA], 0, 0, 0);
+                                acc16[r][nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1_, acc16[r][nh][mt][1], 0, 0, 0);
                             }
                         }
                 }
@@ -399,63 +365,6 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (active && !S16) {
-            const char* st = smem + (c & 1) * IN_BYTES;
-            const f32x4* sw = reinterpret_cast<const f32x4*>(smem + WRING + (c & 1) * W_BYTES);
-            auto pix_frag = [&](int r, int dx, int plane) -> f32x4 {
-                return *reinterpret_cast<const f32x4*>(st + (p_off[dx] ^ (plane << 5)) + r * (PW * 64));
-            };
-            f32x4 P[2][RW + 2][2];
-            f32x4 Wf[2][NT][2];   // [buffer][cout group][hi | lo]; slab t starts W_ITEMS1 items after slab t-1
-#pragma unroll
-            for (int r = 0; r < RW + 2; ++r) { P[0][r][0] = pix_frag(r, 0, 0); P[0][r][1] = pix_frag(r, 0, 1); }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                Wf[0][t][0] = sw[w_off + t * W_ITEMS1];
-                Wf[0][t][1] = sw[w_off + t * W_ITEMS1 + 64];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s = 0; s < 9; ++s) {
-                const int dx = s / 3, dy = s - dx * 3;
-                if (s + 1 < 9) {
-                    const int dx1 = (s + 1) / 3, dy1 = (s + 1) - dx1 * 3;
-                    const int tap1 = dy1 * 3 + dx1;
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        Wf[(s + 1) & 1][t][0] = sw[w_off + t * W_ITEMS1 + tap1 * 128];
-                        Wf[(s + 1) & 1][t][1] = sw[w_off + t * W_ITEMS1 + tap1 * 128 + 64];
-                    }
-                }
-                if (dy == 0 && dx < 2) {
-#pragma unroll
-                    for (int r = 0; r < RW + 2; ++r) {
-                        P[(dx + 1) & 1][r][0] = pix_frag(r, dx + 1, 0);
-                        P[(dx + 1) & 1][r][1] = pix_frag(r, dx + 1, 1);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (NESR_ABL & 8) {
-#pragma unroll
-                    for (int r = 0; r < RW; ++r) acc[r][0][0][0] += Wf[s & 1][0][0][0] + Wf[s & 1][NT - 1][1][0] + P[dx & 1][r + dy][0][0] + P[dx & 1][r + dy][1][0];
-                    continue;
-                }
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f16x8 wh = __builtin_bit_cast(f16x8, Wf[s & 1][t][0]), wl = __builtin_bit_cast(f16x8, Wf[s & 1][t][1]);
-#pragma unroll
-                    for (int r = 0; r < RW; ++r)
-                        acc[r][t][XA] = MFMA32(wh, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][1]), acc[r][t][XA], 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < RW; ++r)
-                        acc[r][t][0] = MFMA32(wh, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][0]), acc[r][t][0], 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < RW; ++r)
-                        acc[r][t][XA] = MFMA32(wl, __builtin_bit_cast(f16x8, P[dx & 1][r + dy][0]), acc[r][t][XA], 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
         STAMP(11 + 4 * c);
     }
     STAMP(2);
@@ -465,163 +374,78 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
 #pragma unroll
         for (int r = 0; r < RW; ++r)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sum += acc[r][0][0][e] + acc[r][NT - 1][XA][e] + acc16[r][e & 1][(e >> 1) & 1][(e >> 2) & (NACC - 1)][e & 3];
+            for (int e = 0; e < 16; ++e) sum += acc16[r][e & 1][(e >> 1) & 1][(e >> 2) & 1][e & 3];
         if (sum == 12345.678f) static_cast<float*>(a.out)[0] = sum;
         return;
     }
 
-    if constexpr (S16) {
-        // ---- epilogue of the 16x16x32 form.  C/D layout: lane (pixel j16, k-group g4) holds couts 16 mt + 4 g4 + i.
-        // v_permlane16_swap of the mt = 0 / mt = 1 values leaves every lane with 8 consecutive couts of its
-        // pixel: base 0 / 16 / 8 / 24 for g4 = 0 / 1 / 2 / 3 (tools/probes/mfma16_layout.hip).
-        const int cb = cb16;
-        const uint16_t* res1 = static_cast<const uint16_t*>(a.res1);
-        const uint16_t* res2 = static_cast<const uint16_t*>(a.res2);
-        uint16_t* out = static_cast<uint16_t*>(a.out);
-        uint16_t* out2 = static_cast<uint16_t*>(a.out2);
-#pragma unroll
-        for (int r = 0; r < RW; ++r)
-#pragma unroll
-            for (int nh = 0; nh < 2; ++nh) {
-                const int Y = y0 + RW * wave + r, X = x0 + 16 * nh + j16;
-                const bool valid = X < a.w_ && Y < a.h;
-                const size_t pix = ((size_t)n * a.h + (Y < a.h ? Y : 0)) * a.w_ + (X < a.w_ ? X : 0);
-                auto at = [&](const Map& mp, int c) -> size_t { return (size_t)(c >> 4) * mp.chunk + pix * mp.pix + (c & 15); };
-                f32x4 v0, v1;   // couts cb .. cb+3, cb+4 .. cb+7
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float e = NACC == 2 ? acc16[r][nh][0][0][i] + acc16[r][nh][0][XA][i] : acc16[r][nh][0][0][i];
-                    const float o = NACC == 2 ? acc16[r][nh][1][0][i] + acc16[r][nh][1][XA][i] : acc16[r][nh][1][0][i];
-                    const auto sw_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(e), __float_as_uint(o), false, false);
-                    v0[i] = __uint_as_float(sw_[0]);
-                    v1[i] = __uint_as_float(sw_[1]);
-                }
-                v0 += bz0;
-                v1 += bz1;
-                if (a.lrelu) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { v0[i] = v0[i] > 0.f ? v0[i] : v0[i] * 0.2f; v1[i] = v1[i] > 0.f ? v1[i] : v1[i] * 0.2f; }
-                }
-                if (res1) {
-                    const f32x4 q0 = ld4_split(res1 + at(a.res1_map, cb)), q1 = ld4_split(res1 + at(a.res1_map, cb + 4));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s1), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s1), q1[i]); }
-                }
-                if (res2) {
-                    const f32x4 q0 = ld4_split(res2 + at(a.res2_map, cb)), q1 = ld4_split(res2 + at(a.res2_map, cb + 4));
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s2), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s2), q1[i]); }
-                }
-                uint2 h0, l0, h1, l1;
-                split4(v0, h0, l0);
-                split4(v1, h1, l1);
-                const uint4 whi = uint4{h0.x, h0.y, h1.x, h1.y}, wlo = uint4{l0.x, l0.y, l1.x, l1.y};
-                if (valid) {
-                    if (out) {
-                        uint16_t* p = out + at(a.out_map, a.out_coff + cb);
-                        store16(p, whi);
-                        store16(p + 16, wlo);
-                    }
-                    if (out2) {
-                        uint16_t* p = out2 + at(a.out2_map, cb);
-                        store16(p, whi);
-                        store16(p + 16, wlo);
-                    }
-                    if (a.cout_real > 0 && cb == 0) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            if (q >= a.cout_real) break;
-                            const float x = v0[q];
-                            if (a.out_nchw) a.out_nchw[(((size_t)n * a.cout_real + q) * a.h + Y) * a.w_ + X] = x;
-                            if (a.out_u8) {
-                                float qv = fminf(fmaxf(x, 0.f), 1.f) * 255.0f;
-                                qv = a.u8_round ? rintf(qv) : truncf(qv);
-                                const int ch = a.u8_flip ? (a.cout_real - 1 - q) : q;
-                                a.out_u8[pix * a.cout_real + ch] = (uint8_t)qv;
-                            }
-                        }
-                    }
-                }
-            }
-        STAMP(3);
-        return;
-    }
-    // ---- epilogue: lane = pixel column m of rows RW*wave + r; regs = 4-channel runs 8g + 4hh of this
-    // workgroup's 32 output channels (network channels 32 cg + ...)
-    const int X = x0 + m;
-    const bool xok = X < a.w_;
-    const int Xc = xok ? X : 0;
+    // ---- epilogue.  C/D layout: lane (pixel j16, k-group g4) holds couts 16 mt + 4 g4 + i.
+    // v_permlane16_swap of the mt = 0 / mt = 1 values leaves every lane with 8 consecutive couts of its
+    // pixel: base 0 / 16 / 8 / 24 for g4 = 0 / 1 / 2 / 3 (tools/probes/mfma16_layout.hip).
+    const int cb = cb16;
     const uint16_t* res1 = static_cast<const uint16_t*>(a.res1);
     const uint16_t* res2 = static_cast<const uint16_t*>(a.res2);
     uint16_t* out = static_cast<uint16_t*>(a.out);
     uint16_t* out2 = static_cast<uint16_t*>(a.out2);
+    bool bad = false;
+    // conv_last: a range failure anywhere upstream in this forward (sticky word, set by earlier launches on this
+    // stream) turns the image into NaN instead of a saturated picture
+    const bool poison = a.cout_real > 0 && a.status && __builtin_nontemporal_load(a.status) != 0u;
 #pragma unroll
     for (int r = 0; r < RW; ++r)
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int cbase = 32 * (cg * NT + t);
-        const int Y = y0 + RW * wave + r;
-        const bool valid = xok && Y < a.h;
-        const size_t pix = ((size_t)n * a.h + (Y < a.h ? Y : 0)) * a.w_ + Xc;
-        // hi half of channel c (lo: +16 elements)
-        auto at = [&](const Map& mp, int c) -> size_t { return (size_t)(c >> 4) * mp.chunk + pix * mp.pix + (c & 15); };
-        f32x4 r1[4], r2[4];
-        if (res1) {
+        for (int nh = 0; nh < 2; ++nh) {
+            const int Y = y0 + RW * wave + r, X = x0 + 16 * nh + j16;
+            const bool valid = X < a.w_ && Y < a.h;
+            const size_t pix = ((size_t)n * a.h + (Y < a.h ? Y : 0)) * a.w_ + (X < a.w_ ? X : 0);
+            auto at = [&](const Map& mp, int c) -> size_t { return (size_t)(c >> 4) * mp.chunk + pix * mp.pix + (c & 15); };
+            f32x4 v0, v1;   // couts cb .. cb+3, cb+4 .. cb+7
 #pragma unroll
-            for (int g = 0; g < 4; ++g) r1[g] = ld4_split(res1 + at(a.res1_map, cbase + 8 * g + 4 * hh));
-        }
-        if (res2) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) r2[g] = ld4_split(res2 + at(a.res2_map, cbase + 8 * g + 4 * hh));
-        }
-        f32x4 v[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float x = (NACC == 2 ? acc[r][t][0][4 * g + q] + acc[r][t][XA][4 * g + q] : acc[r][t][0][4 * g + q]) + bs[t][g][q];
-                if (a.lrelu) x = x > 0.f ? x : x * 0.2f;
-                if (res1) x = __fadd_rn(__fmul_rn(x, a.s1), r1[g][q]);
-                if (res2) x = __fadd_rn(__fmul_rn(x, a.s2), r2[g][q]);
-                v[g][q] = x;
+            for (int i = 0; i < 4; ++i) {
+                const float e = fmaf(acc16[r][nh][0][1][i], LO_INV, acc16[r][nh][0][0][i]);
+                const float o = fmaf(acc16[r][nh][1][1][i], LO_INV, acc16[r][nh][1][0][i]);
+                const auto sw_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(e), __float_as_uint(o), false, false);
+                v0[i] = __uint_as_float(sw_[0]);
+                v1[i] = __uint_as_float(sw_[1]);
             }
-        // widen to 8 channels per lane (permlane32_swap, see conv3x3_bf16.hip): the lower half-wave ends
-        // up with channels 16j..16j+7 of its pixel, the upper one with 16j+8..16j+15; once per plane
-        uint4 whi[2], wlo[2];
+            v0 += bz0;
+            v1 += bz1;
+            if (a.lrelu) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            uint2 eh, el, oh, ol;
-            split4(v[2 * j], eh, el);
-            split4(v[2 * j + 1], oh, ol);
-            const auto hx = __builtin_amdgcn_permlane32_swap(eh.x, oh.x, false, false);
-            const auto hy = __builtin_amdgcn_permlane32_swap(eh.y, oh.y, false, false);
-            const auto lx = __builtin_amdgcn_permlane32_swap(el.x, ol.x, false, false);
-            const auto ly = __builtin_amdgcn_permlane32_swap(el.y, ol.y, false, false);
-            whi[j] = uint4{hx[0], hy[0], hx[1], hy[1]};
-            wlo[j] = uint4{lx[0], ly[0], lx[1], ly[1]};
-        }
-        if (valid) {
-            if (out) {
+                for (int i = 0; i < 4; ++i) { v0[i] = v0[i] > 0.f ? v0[i] : v0[i] * 0.2f; v1[i] = v1[i] > 0.f ? v1[i] : v1[i] * 0.2f; }
+            }
+            if (res1) {
+                const f32x4 q0 = ld4_split(res1 + at(a.res1_map, cb)), q1 = ld4_split(res1 + at(a.res1_map, cb + 4));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    uint16_t* p = out + at(a.out_map, a.out_coff + cbase + 16 * j + 8 * hh);
-                    store16(p, whi[j]);
-                    store16(p + 16, wlo[j]);
+                for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s1), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s1), q1[i]); }
+            }
+            if (res2) {
+                const f32x4 q0 = ld4_split(res2 + at(a.res2_map, cb)), q1 = ld4_split(res2 + at(a.res2_map, cb + 4));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s2), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s2), q1[i]); }
+            }
+            if (!valid) continue;
+            if (out || out2) {
+                uint2 h0, l0, h1, l1;
+                split4(v0, h0, l0, bad);
+                split4(v1, h1, l1, bad);
+                const uint4 whi = uint4{h0.x, h0.y, h1.x, h1.y}, wlo = uint4{l0.x, l0.y, l1.x, l1.y};
+                if (out) {
+                    uint16_t* p = out + at(a.out_map, a.out_coff + cb);
+                    store16(p, whi);
+                    store16(p + 16, wlo);
+                }
+                if (out2) {
+                    uint16_t* p = out2 + at(a.out2_map, cb);
+                    store16(p, whi);
+                    store16(p + 16, wlo);
                 }
             }
-            if (out2) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    uint16_t* p = out2 + at(a.out2_map, cbase + 16 * j + 8 * hh);
-                    store16(p, whi[j]);
-                    store16(p + 16, wlo[j]);
-                }
-            }
-            if (a.cout_real > 0 && hh == 0 && cbase == 0) {
+            if (a.cout_real > 0 && cb == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (q >= a.cout_real) break;
-                    const float x = v[0][q];
+                    const float x = poison ? __builtin_nanf("") : v0[q];
                     if (a.out_nchw) a.out_nchw[(((size_t)n * a.cout_real + q) * a.h + Y) * a.w_ + X] = x;
                     if (a.out_u8) {
                         float qv = fminf(fmaxf(x, 0.f), 1.f) * 255.0f;
@@ -632,7 +456,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
                 }
             }
         }
-    }
+    if (bad && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     STAMP(3);
 #if NESR_ABL & 64
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -640,19 +464,19 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW == 2 ? 3 : DMAW ? (WAVES 
 #endif
 }
 
-template <int RW, int ISLOTS, int DMAW, int NACC, int NT>
+template <int DMAW>
 hipError_t launch_split(const ConvArgs& a, hipStream_t s) {
-    typedef Geo<RW, DMAW> G;
-    constexpr size_t shm = (size_t)ISLOTS * G::IN_BYTES + 2 * (size_t)(W_ITEMS1 * NT * 16);
+    typedef Geo<DMAW> G;
+    constexpr size_t shm = (size_t)ISLOTS * G::IN_BYTES + 2 * (size_t)W_BYTES;
     static unsigned long long attr_done = 0;
     {
-        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_f16x2_kernel<RW, ISLOTS, DMAW, NACC, NT>), shm, attr_done);
+        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_f16x2_kernel<DMAW>), shm, attr_done);
         if (e != hipSuccess) return e;
     }
-    const long total = (long)((a.w_ + TW - 1) / TW) * ((a.h + G::TH - 1) / G::TH) * a.n * (a.coutp / (32 * NT));
+    const long total = (long)((a.w_ + TW - 1) / TW) * ((a.h + G::TH - 1) / G::TH) * a.n * (a.coutp / 32);
     if (total <= 0) return hipSuccess;
     if (total > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((conv3x3_f16x2_kernel<RW, ISLOTS, DMAW, NACC, NT>), dim3((unsigned)total), dim3(G::LAUNCH_THREADS), shm, s, a);
+    hipLaunchKernelGGL((conv3x3_f16x2_kernel<DMAW>), dim3((unsigned)total), dim3(G::LAUNCH_THREADS), shm, s, a);
     return hipGetLastError();
 }
 
@@ -680,12 +504,12 @@ void pack_weights_f16x2(const float* oihw, int cout, int cin, int cin_p, int cou
     for (int o = 0; o < cout; ++o)
         for (int ci = 0; ci < cin; ++ci)
             for (int tap = 0; tap < 9; ++tap) {
-                float wv = oihw[((size_t)o * cin + ci) * 9 + tap];
-                wv = wv > 65504.f ? 65504.f : (wv < -65504.f ? -65504.f : wv);
+                // |w| <= 65504 and finite: nesr_finalize_weights rejects anything else (NESR_ERR_RANGE)
+                const float wv = oihw[((size_t)o * cin + ci) * 9 + tap];
                 const uint16_t hi = f2h(wv);
-                const uint16_t lo = f2h(wv - h2f(hi));
+                const uint16_t lo = f2h((wv - h2f(hi)) * LO_SCALE);
                 const int c = ci / 16, kh = (ci % 16) / 8, kk = ci % 8;
-                const size_t slab = ((size_t)c * groups + o / 32) * (size_t)(W_ITEMS1 * 8);
+                const size_t slab = ((size_t)c * groups + o / 32) * (size_t)(W_ITEMS * 8);
                 const size_t ihi = slab + ((((size_t)tap * 2 + 0) * 2 + kh) * 32 + o % 32) * 8 + kk;
                 const size_t ilo = slab + ((((size_t)tap * 2 + 1) * 2 + kh) * 32 + o % 32) * 8 + kk;
                 dst[ihi] = hi;
@@ -698,18 +522,10 @@ hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s) {
     if ((long long)a.in_h * a.in_w >= (1ll << 26)) return hipErrorInvalidValue;   // 32-bit byte offsets inside one image chunk
     if (a.in_map.pix != 32 || (a.out && (a.out_map.pix % 32 || a.out_coff % 16))) return hipErrorInvalidValue;
     if ((a.out_nchw || a.out_u8) && (a.coutp != 32 || a.cout_real < 1 || a.cout_real > 4)) return hipErrorInvalidValue;
-    // 8x32-px tiles, two workgroups per CU.  The 16x32-px form (one workgroup per CU, 30 % less DMA traffic
-    // per MFMA) stays behind NESR_SPLIT_TILE=16: with nothing else on the CU to run under its DMA issue and
-    // epilogue it measured 21 % slower (5 % slower as 8 waves, -DNESR_SPLIT_WAVES=8) on 12 tiles of 532x532.
-    static const int force = [] { const char* e = getenv("NESR_SPLIT_TILE"); return e ? atoi(e) : 0; }();   // 8 | 16 (rows)
-    if (force == 16) return launch_split<RW_L, 2, 0, 2, 1>(a, s);
-    if (force == 164) return launch_split<RW_L, 2, 4, 1, 1>(a, s);   // 16x32 tiles + 4 DMA waves
-    static const int nt2 = [] { const char* e = getenv("NESR_SPLIT_NT2"); return e ? atoi(e) : 0; }();
-    if (nt2 && a.coutp == 64) return launch_split<RW_S, 2, 4, 1, 2>(a, s);   // 64 couts per workgroup + 4 DMA waves
-    // launches that give a CU at most one workgroup (a 512x512 frame's 32-channel layers): four extra waves
-    // issue the DMAs, so the MFMA waves never stall on LDS-DMA issue (~85 cycles each, 10 per chunk and wave;
-    // in-kernel stamps: -15 % per K-chunk).  With two workgroups per CU the other workgroup already fills
-    // those gaps and the extra waves only cost occupancy (measured +21 % on 6 tiles of 532x532).
+    // 8x32-px tiles.  Launches that give a CU at most one workgroup (a 512x512 frame's 32-channel layers): four
+    // extra waves issue the DMAs, so the MFMA waves never stall on LDS-DMA issue (~85 cycles each, 10 per chunk
+    // and wave; in-kernel stamps: -15 % per K-chunk).  With two workgroups per CU the other workgroup already
+    // fills those gaps and the extra waves only cost occupancy (measured +21 % on 6 tiles of 532x532).
     static const int cus = [] {
         int dev = 0, n = 256;
         if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -721,10 +537,7 @@ hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s) {
     // workgroups (166 registers) keep a second kernel's workgroups off the CU (2 frames in flight: 158 -> 166 MP/s
     // without them; one frame alone: 134 -> 138 MP/s with them)
     const bool producer = dmaw >= 0 ? dmaw > 0 : (t1 <= cus && !a.shared_device);
-    constexpr int NA = WAVES == 8 ? 1 : 2;   // the 8-wave build has 128 registers per wave
-    static const int d2 = [] { const char* e = getenv("NESR_SPLIT_D2"); return e ? atoi(e) : 0; }();
-    if (d2 && !producer) return launch_split<RW_S, 2, 2, 1, 1>(a, s);   // two workgroups per CU, each 4 MFMA + 2 DMA waves (<= 168 registers)
-    return producer ? launch_split<RW_S, 2, 4, NA, 1>(a, s) : launch_split<RW_S, 2, 0, NA, 1>(a, s);
+    return producer ? launch_split<4>(a, s) : launch_split<0>(a, s);
 }
 
 }  // namespace nesr

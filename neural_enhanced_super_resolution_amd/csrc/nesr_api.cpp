@@ -78,6 +78,8 @@ struct nesr_ctx {
     unsigned* last_sync = nullptr;   // abort word of the most recent persistent launch   // device copy of the trunk's layer table (persistent trunk kernel)
     int trunk_mode = 0;              // 0 auto, 1 per-layer launches, 2 persistent kernel
     int shared_device = 0;           // nesr_set_concurrent: other contexts run on the device at the same time
+    unsigned* d_status = nullptr;    // sticky range word of the f16-pair path (ConvArgs::status)
+    unsigned* h_status = nullptr;    // pinned landing word of nesr_check_range
     FwState band;                    // the banded evaluation in progress (nesr_band_*)
     bool band_valid = false;
     // kernel timing hook
@@ -167,6 +169,7 @@ ConvArgs base_args(const nesr_ctx* c, const Layer& L, int N, int h, int w) {
     a.s1 = a.s2 = 1.f;
     a.cout_real = 0;
     a.shared_device = c->shared_device;
+    a.status = c->dtype == NESR_DTYPE_F32_SPLIT ? c->d_status : nullptr;
     return a;
 }
 
@@ -222,6 +225,7 @@ int fw_first(nesr_ctx* c, const FwState& F, const float* x_f32, const uint8_t* x
     p.dst_map = F.m_in;
     p.cp = c->layers[0].cin_p;
     p.bf16 = c->kind();
+    p.status = c->dtype == NESR_DTYPE_F32_SPLIT ? c->d_status : nullptr;
     HIP_TRY(launch_pack_input(p, s));
     ConvArgs a = base_args(c, c->layers[0], F.N, F.h, F.w);
     a.in = ws + F.L.in; a.in_map = F.m_in;
@@ -381,7 +385,18 @@ int nesr_create(nesr_ctx** out, int device_id, int conv_first_in_ch, int unshuff
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device_id < 0 || device_id >= ndev) return fail(NESR_ERR_ARG, "no such device " + std::to_string(device_id));
+    HIP_TRY(hipSetDevice(device_id));
+    unsigned* d_status = nullptr;
+    unsigned* h_status = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_status, 256));
+    if (hipMemset(d_status, 0, 256) != hipSuccess || hipHostMalloc((void**)&h_status, 64, hipHostMallocDefault) != hipSuccess) {
+        (void)hipFree(d_status);
+        return fail(NESR_ERR_HIP, "allocating the context's status words failed");
+    }
+    *h_status = 0;
     nesr_ctx* c = new nesr_ctx();
+    c->d_status = d_status;
+    c->h_status = h_status;
     c->device = device_id;
     c->cin0 = conv_first_in_ch;
     c->unshuffle = unshuffle;
@@ -463,6 +478,20 @@ int nesr_finalize_weights(nesr_ctx* c) {
         if (!L.has_b && nmiss++ < 4) missing += " " + L.name + ".bias";
     }
     if (nmiss) return fail(NESR_ERR_STATE, "Missing key(s) in state_dict (" + std::to_string(nmiss) + "):" + missing);
+    // non-finite parameters are refused for every dtype; the f16-pair form also needs |w| <= 65504 (the hi half
+    // is an f16) -- never a silently clamped weight
+    for (const Layer& L : c->layers) {
+        const float lim = c->dtype == NESR_DTYPE_F32_SPLIT ? 65504.f : INFINITY;
+        for (int t = 0; t < 2; ++t) {
+            const std::vector<float>& v = t ? L.b : L.w;
+            const float blim = t ? INFINITY : lim;   // biases are added in f32
+            for (size_t i = 0; i < v.size(); ++i)
+                if (!(std::fabs(v[i]) <= blim) || !std::isfinite(v[i]))
+                    return fail(NESR_ERR_RANGE, L.name + (t ? ".bias" : ".weight") + "[" + std::to_string(i) + "] = " + std::to_string(v[i]) +
+                                                    (std::isfinite(v[i]) ? ": |w| > 65504 does not fit the f16-pair form of compute_dtype f32 "
+                                                                           "(use f32-winograd or f32-direct)" : ": non-finite parameter"));
+        }
+    }
     HIP_TRY(hipSetDevice(c->device));
     const bool bf = c->dtype == NESR_DTYPE_BF16;
     const bool sp = c->dtype == NESR_DTYPE_F32_SPLIT;
@@ -659,6 +688,24 @@ int nesr_check_status(nesr_ctx* c) {
         HIP_TRY(hipMemcpy(&flag, c->last_sync, 4, hipMemcpyDeviceToHost));
         if (flag) return fail(NESR_ERR_HIP, "persistent trunk kernel aborted: a neighbour wait timed out (workgroups not co-resident?)");
     }
+    return nesr_check_range(c, nullptr);
+}
+
+int nesr_check_range(nesr_ctx* c, void* stream) {
+    if (!c) return fail(NESR_ERR_ARG, "null ctx");
+    if (c->dtype != NESR_DTYPE_F32_SPLIT) return NESR_OK;   // the other forms compute in formats with f32's range
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIP_TRY(hipMemcpyAsync(c->h_status, c->d_status, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (*c->h_status) {
+        HIP_TRY(hipMemsetAsync(c->d_status, 0, 4, s));   // reported once; the next forward starts clean
+        HIP_TRY(hipStreamSynchronize(s));
+        *c->h_status = 0;
+        return fail(NESR_ERR_RANGE, "an input or activation of the f16-pair fp32 path was non-finite or exceeded 65504 in magnitude: "
+                                    "the float output of that forward is NaN, an 8-bit output is invalid (use compute_dtype "
+                                    "f32-winograd or f32-direct for such data)");
+    }
     return NESR_OK;
 }
 
@@ -671,6 +718,8 @@ void nesr_destroy(nesr_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->d_weights) (void)hipFree(c->d_weights);
     if (c->d_trunk) (void)hipFree(c->d_trunk);
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->h_status) (void)hipHostFree(c->h_status);
     delete c;
 }
 
@@ -786,12 +835,14 @@ int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, in
     HIP_TRY(scratch.take((void**)&d_out, out_bytes));
     HIP_TRY(scratch.take((void**)&d_zero, 256));
     HIP_TRY(hipMemset(d_zero, 0, 256));
+    unsigned* d_status = reinterpret_cast<unsigned*>(d_zero + 128);   // the upper half of the zero page is never a DMA source (>= 16 B needed)
     HIP_TRY(hipMemcpy(d_w, hw.data(), hw.size(), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_b, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
     PackArgs p;
     std::memset(&p, 0, sizeof(p));
     const Map mi = make_map(kind, cin_p, (size_t)N * H * W), mo = make_map(kind, cout_p, (size_t)N * ho * wo);
     p.src = x_dev; p.n = N; p.c = Cin; p.hin = H; p.win = W; p.unshuffle = 1; p.dst = d_in; p.dst_map = mi; p.cp = cin_p; p.bf16 = kind;
+    p.status = sp ? d_status : nullptr;
     HIP_TRY(launch_pack_input(p, s));
     ConvArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -801,9 +852,17 @@ int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, in
     a.out = d_out; a.out_map = mo; a.out_coff = 0;
     a.lrelu = lrelu ? 1 : 0; a.s1 = a.s2 = 1.f;
     a.zeros = d_zero;
+    a.status = sp ? d_status : nullptr;
     HIP_TRY(sp ? launch_conv3x3_f16x2(a, s) : bf ? launch_conv3x3_bf16(a, s) : (wino ? launch_conv3x3_wino_f32(a, s) : launch_conv3x3_f32(a, s)));
     HIP_TRY(launch_nhwc_to_nchw(d_out, kind, mo, N, Cout, ho, wo, static_cast<float*>(y_dev), s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (sp) {
+        unsigned flag = 0;
+        HIP_TRY(hipMemcpy(&flag, d_status, 4, hipMemcpyDeviceToHost));
+        if (flag) return fail(NESR_ERR_RANGE, "input or output of the layer was non-finite or exceeded 65504 in magnitude (f16-pair form)");
+        for (size_t i = 0; i < (size_t)Cout * Cin * 9; ++i)
+            if (!(std::fabs(w_host[i]) <= 65504.f)) return fail(NESR_ERR_RANGE, "weight does not fit the f16-pair form (|w| > 65504 or non-finite)");
+    }
     return NESR_OK;
 }
 

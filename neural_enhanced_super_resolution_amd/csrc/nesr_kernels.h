@@ -67,6 +67,9 @@ struct ConvArgs {
     int u8_flip, u8_round;
     // >= 16 bytes of device zeros: LDS-DMA source for out-of-image pixels (bf16 large-tile kernel)
     const void* zeros;
+    // f16-pair path: sticky device word set when a value does not fit the (hi, lo) pair (|x| > 65504 or not
+    // finite); conv_last reads it and writes NaN instead of a saturated image.  May be null.
+    unsigned* status;
     // host-side hint, not read by kernels: other contexts' launches share the device with this one (frames or tile
     // groups in flight on several streams) -- prefer kernel forms whose workgroups leave room on a CU
     int shared_device;
@@ -90,8 +93,8 @@ hipError_t launch_conv3x3_bf16_xl(const ConvArgs& a, hipStream_t s);    // conv3
 size_t packed_weight_elems_bf16(int cin_p, int coutp);
 void pack_weights_bf16(const float* oihw, int cout, int cin, int cin_p, int coutp, uint16_t* dst);
 
-// f32 path on the f16 matrix cores (conv3x3_f16x2.hip): operands as exact-sum (hi, lo) half pairs, three
-// MFMAs per product, f32 accumulation.  Activations: channel-blocked [C/16][pixels][16 hi | 16 lo]
+// f32 path on the f16 matrix cores (conv3x3_f16x2.hip): operands as (hi, lo) half pairs, x = hi + lo * 2^-11,
+// three MFMAs per product, f32 accumulation.  Activations: channel-blocked [C/16][pixels][16 hi | 16 lo]
 // (Map in 2-byte units: pix = 32, chunk = pixels * 32).
 hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s);
 size_t packed_weight_elems_f16x2(int cin_p, int coutp);   // in 2-byte units
@@ -132,6 +135,7 @@ struct PackArgs {
     Map dst_map;
     int cp;
     int bf16;            // destination layout: 0 f32 NHWC (KG = 8), 1 bf16 blocked (KG = 16), 2 f16 hi|lo blocked (KG = 16)
+    unsigned* status;    // as ConvArgs::status (layout 2 only); may be null
 };
 hipError_t launch_pack_input(const PackArgs& a, hipStream_t s);
 

@@ -18,22 +18,25 @@ __device__ inline uint16_t f2bf(float f) {
     return *reinterpret_cast<uint16_t*>(&b);
 }
 __device__ inline float bf2f(uint16_t u) { return __uint_as_float(((unsigned)u) << 16); }
-// f32 -> exact-sum (hi, lo) half pair of the f16x2 path (conv3x3_f16x2.hip)
-__device__ inline void f2hl(float f, uint16_t& hi, uint16_t& lo) {
+// f32 -> (hi, lo) half pair of the f16x2 path, x = hi + lo * 2^-11 (conv3x3_f16x2.hip); returns false if x
+// does not fit (|x| > 65504, NaN, Inf: clamped, and the caller raises the context's sticky range flag)
+__device__ inline bool f2hl(float f, uint16_t& hi, uint16_t& lo) {
     const float x = fminf(fmaxf(f, -65504.f), 65504.f);
     const _Float16 h = (_Float16)x;
-    const _Float16 l = (_Float16)(x - (float)h);
+    const _Float16 l = (_Float16)((x - (float)h) * 2048.f);
     hi = __builtin_bit_cast(uint16_t, h);
     lo = __builtin_bit_cast(uint16_t, l);
+    return __builtin_fabsf(f) <= 65504.f;
 }
 __device__ inline float hl2f(uint16_t hi, uint16_t lo) {
-    return (float)__builtin_bit_cast(_Float16, hi) + (float)__builtin_bit_cast(_Float16, lo);
+    return fmaf((float)__builtin_bit_cast(_Float16, lo), 1.f / 2048.f, (float)__builtin_bit_cast(_Float16, hi));
 }
 
 __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
     const int s = a.unshuffle;
     const int ho = a.hin / s, wo = a.win / s;
     const size_t total = (size_t)a.n * ho * wo;
+    bool bad = false;
     for (size_t pix = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(pix % wo);
         const int y = (int)((pix / wo) % ho);
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
             const size_t idx = (size_t)(co / kg) * a.dst_map.chunk + pix * a.dst_map.pix + (co % kg);
             if (a.bf16 == 2) {
                 uint16_t hi, lo;
-                f2hl(v, hi, lo);
+                bad |= !f2hl(v, hi, lo);
                 static_cast<uint16_t*>(a.dst)[idx] = hi;
                 static_cast<uint16_t*>(a.dst)[idx + 16] = lo;
             } else if (a.bf16)
@@ -67,6 +70,7 @@ __global__ __launch_bounds__(256) void pack_input_kernel(PackArgs a) {
                 static_cast<float*>(a.dst)[idx] = v;
         }
     }
+    if (bad && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* src, int bf16, Map map, int n, int c, int h, int w, float* dst) {

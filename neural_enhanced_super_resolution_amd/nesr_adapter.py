@@ -44,10 +44,18 @@ def gaussian_blur3x3_u8(img):
     return ((s + 8) >> 4).clamp_(0, 255).to(torch.uint8).squeeze(0).permute(1, 2, 0)
 
 
+def _u8_on(image_rgb, device):
+    """HWC uint8 ndarray or tensor -> tensor on `device` (a tensor already there is used as it is: the
+    iteration loop keeps its frames on the GPU)."""
+    if isinstance(image_rgb, torch.Tensor):
+        return image_rgb.to(device)
+    return torch.as_tensor(np.ascontiguousarray(image_rgb)).to(device)
+
+
 def build_12channel(image_rgb, device):
     """nesr.py:851-882: RGB u8 -> [1, 12, H, W] float32 on device
     = [bgr/255, clamp(1.1 bgr/255), clamp(0.9 bgr/255), GaussianBlur3x3(bgr)/255]."""
-    bgr = torch.as_tensor(np.ascontiguousarray(image_rgb)).to(device).flip(2)            # cv2.COLOR_RGB2BGR
+    bgr = _u8_on(image_rgb, device).flip(2)                                                # cv2.COLOR_RGB2BGR
     t = normalize_u8_on_device(bgr.permute(2, 0, 1))                                       # /255.0
     blurred = normalize_u8_on_device(gaussian_blur3x3_u8(bgr).permute(2, 0, 1))
     return torch.cat([t, torch.clamp(t * 1.1, 0, 1), torch.clamp(t * 0.9, 0, 1), blurred], 0).unsqueeze(0)
@@ -55,7 +63,7 @@ def build_12channel(image_rgb, device):
 
 def build_3channel_x4(image_rgb, device):
     """nesr.py:915-927: RGB u8 -> [1, 12, H, W] = the BGR/255 image repeated 4 times."""
-    bgr = torch.as_tensor(np.ascontiguousarray(image_rgb)).to(device).flip(2)
+    bgr = _u8_on(image_rgb, device).flip(2)
     t = normalize_u8_on_device(bgr.permute(2, 0, 1))
     return torch.cat([t, t, t, t], 0).unsqueeze(0)
 
@@ -67,6 +75,16 @@ def quantize_trunc_to_rgb(output):
     return q.flip(2)
 
 
+def _to_host(upscaler, t):
+    """Device-to-host copy + the range check of the f16-pair fp32 form (a NaN image is an error here; the
+    reference's np.clip(...).astype(uint8) would turn NaN pixels into garbage silently, nesr.py:897-898)."""
+    host = t.cpu().numpy()
+    check = getattr(upscaler.model, "check_range", None)
+    if check is not None:
+        check()
+    return host
+
+
 @torch.no_grad()
 def apply_esrgan_12channel(upscaler, image_rgb, as_numpy=True):
     """_apply_esrgan_12channel (nesr.py:845-903) with every step on the GPU."""
@@ -74,7 +92,7 @@ def apply_esrgan_12channel(upscaler, image_rgb, as_numpy=True):
     model.eval()
     y = model(build_12channel(image_rgb, upscaler.device))
     q = quantize_trunc_to_rgb(y)
-    return q.cpu().numpy() if as_numpy else q
+    return _to_host(upscaler, q) if as_numpy else q
 
 
 @torch.no_grad()
@@ -84,7 +102,7 @@ def apply_esrgan_3channel(upscaler, image_rgb, as_numpy=True):
     model.eval()
     y = model(build_3channel_x4(image_rgb, upscaler.device))
     q = quantize_trunc_to_rgb(y)
-    return q.cpu().numpy() if as_numpy else q
+    return _to_host(upscaler, q) if as_numpy else q
 
 
 # ----------------------------------------------------------------------------- Lanczos-4 resize
@@ -128,12 +146,13 @@ def lanczos4_resize_u8(img, out_h, out_w):
 
 # ----------------------------------------------------------------------------- NESR tiler + dispatcher
 @torch.no_grad()
-def process_with_tiling(processor, image_rgb, tile_size, padding, upscale_factor, device):
+def process_with_tiling(processor, image_rgb, tile_size, padding, upscale_factor, device, as_numpy=True):
     """_process_with_tiling (nesr.py:311-475): `processor(tile_rgb_u8 ndarray|tensor) -> uint8 tensor`.
-    Returns an HWC uint8 RGB ndarray of size int(h*uf) x int(w*uf)."""
+    Returns an HWC uint8 RGB image of size int(h*uf) x int(w*uf) (ndarray, or the device tensor)."""
     h, w, c = image_rgb.shape
     if h <= tile_size and w <= tile_size:
-        return processor(image_rgb).cpu().numpy()
+        out = processor(image_rgb)
+        return out.cpu().numpy() if as_numpy else out
     nth, ntw = math.ceil(h / tile_size), math.ceil(w / tile_size)
     out_h, out_w = int(h * upscale_factor), int(w * upscale_factor)
     canvas = torch.zeros((out_h, out_w, c), dtype=torch.uint8, device=device)
@@ -172,13 +191,18 @@ def process_with_tiling(processor, image_rgb, tile_size, padding, upscale_factor
             if region.shape[0] != oh or region.shape[1] != ow:
                 region = lanczos4_resize_u8(region, oh, ow)     # cv2.resize(..., INTER_LANCZOS4), nesr.py:438-443
             canvas[oy0:oy1, ox0:ox1] = region
-    return canvas.cpu().numpy()
+    return canvas.cpu().numpy() if as_numpy else canvas
 
 
-def apply_esrgan(upscaler, image_rgb, config=None, device_kind="cuda"):
+LARGE_IMAGE_MP = 16      # nesr.py:787: above this many "megapixels" (px / 1024^2) tiling and 3-channel mode are forced
+
+
+def apply_esrgan(upscaler, image_rgb, config=None, device_kind="cuda", as_numpy=True, trace=None, large_mp=LARGE_IMAGE_MP):
     """_apply_esrgan (nesr.py:754-813): the reference's dispatch, minus its fallback ladder.
     config keys as the reference's: enable_tiling, force_3channel, max_tile_size, upscale_factor,
-    cuda_megapixel_threshold (the reference's literal default for cuda is 8)."""
+    cuda_megapixel_threshold (the reference's literal default for cuda is 8).  `large_mp` is the reference's
+    literal 16 (a parameter only so that tests can reach that branch with small frames); `trace`, if a list,
+    receives one dict describing the route taken."""
     cfg = {"enable_tiling": True, "force_3channel": False, "max_tile_size": 512, "upscale_factor": 2.0}
     cfg.update(config or {})
     h, w, _ = image_rgb.shape
@@ -189,10 +213,48 @@ def apply_esrgan(upscaler, image_rgb, config=None, device_kind="cuda"):
             device_kind, cfg.get("cuda_megapixel_threshold", 8))
         use_tiling = megapixels > thr
     use_3ch = cfg["force_3channel"]
-    if megapixels > 16:
+    if megapixels > large_mp:
         use_tiling, use_3ch = True, True
+    model = upscaler.model
+    calls0 = getattr(model, "calls", None)
     one = (lambda t: apply_esrgan_3channel(upscaler, t, as_numpy=False)) if use_3ch else \
           (lambda t: apply_esrgan_12channel(upscaler, t, as_numpy=False))
     if use_tiling:
-        return process_with_tiling(one, image_rgb, cfg["max_tile_size"], 16, cfg["upscale_factor"], upscaler.device)
-    return one(image_rgb).cpu().numpy()
+        out = process_with_tiling(one, image_rgb, cfg["max_tile_size"], 16, cfg["upscale_factor"], upscaler.device, as_numpy=False)
+    else:
+        out = one(image_rgb)
+    if trace is not None:
+        trace.append({"in_shape": (h, w), "out_shape": tuple(out.shape[:2]), "tiled": bool(use_tiling), "three_channel": bool(use_3ch),
+                      "model_calls": None if calls0 is None else model.calls - calls0})
+    if as_numpy:
+        return _to_host(upscaler, out)
+    return out
+
+
+def enhance_iterations(upscaler, image_rgb, config=None, device_kind="cuda", preprocess=None, postprocess=None,
+                       trace=None, large_mp=LARGE_IMAGE_MP):
+    """The iteration loop of SuperResolutionPipeline.enhance_image (nesr.py:516-633) around its ESRGAN stage:
+
+        for iteration in range(config['iterations']):           nesr.py:516
+            current = _preprocess_image(current)                 nesr.py:537   -> `preprocess` (NL-means + CLAHE; None = off)
+            esrgan_result = _apply_esrgan(current)               nesr.py:566   -> apply_esrgan above
+            current = _ensemble_results([esrgan_result])         nesr.py:596   one model: the identity (nesr.py:1035-1036)
+            current = _postprocess_image(current)                nesr.py:616   -> `postprocess` (adaptive unsharp; None = off)
+
+    with diffusion and segmentation off (BASELINE.json configs[4]: `--no_diffusion`; the SegFormer weights are a
+    network fetch).  Frames stay on the GPU between iterations; the final frame is returned as an HWC uint8 RGB
+    ndarray.  A backend failure raises (the reference would hand back a bicubic resize, nesr.py:835-843); `trace`
+    receives one dict per iteration with the route and the number of network evaluations, so a caller can assert
+    that the network really ran."""
+    cfg = {"iterations": 3, "upscale_factor": 2.0}
+    cfg.update(config or {})
+    current = image_rgb
+    for iteration in range(int(cfg["iterations"])):
+        if preprocess is not None:
+            current = preprocess(current)
+        current = apply_esrgan(upscaler, current, cfg, device_kind, as_numpy=False, trace=trace, large_mp=large_mp)
+        if trace is not None:
+            trace[-1]["iteration"] = iteration
+        if postprocess is not None:
+            current = postprocess(current)
+    return _to_host(upscaler, current) if isinstance(current, torch.Tensor) else current

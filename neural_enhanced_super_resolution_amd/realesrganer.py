@@ -287,7 +287,14 @@ class RealESRGANer:
         out = self._run()                                                            # [1,3,H*s,W*s] RGB
         out = out.data.squeeze(0).float().clamp_(0, 1)
         q = (out.flip(0).permute(1, 2, 0) * 255.0).round().to(torch.uint8)           # RGB->BGR, CHW->HWC, x255, round
-        return q.contiguous().cpu().numpy()
+        host = q.contiguous().cpu().numpy()
+        self._check_range()
+        return host
+
+    def _check_range(self, slot=None):
+        """After a device-to-host copy: an out-of-range forward of the f16-pair fp32 form raises here."""
+        if isinstance(self.model, RRDBNet):
+            self.model.check_range(slot)
 
     @torch.no_grad()
     def enhance_many(self, imgs, inflight=4):
@@ -311,6 +318,8 @@ class RealESRGANer:
         def finish(entry):
             idx, host, ev = entry
             ev.synchronize()
+            with torch.cuda.stream(streams[idx % inflight]):
+                self._check_range(idx % inflight)
             results[idx] = (host.numpy().copy(), "RGB")
 
         for i, img in enumerate(imgs):
@@ -356,6 +365,7 @@ class RealESRGANer:
         self.pre_process(np.ascontiguousarray(img))
         output_img = self._run()
         output_img = output_img.data.squeeze().float().cpu().clamp_(0, 1).numpy()
+        self._check_range()
         output_img = np.transpose(output_img[[2, 1, 0], :, :], (1, 2, 0))
         if img_mode == "L":
             output_img = _bgr2gray(output_img)
@@ -364,6 +374,7 @@ class RealESRGANer:
             self.pre_process(np.ascontiguousarray(alpha))
             output_alpha = self._run()
             output_alpha = output_alpha.data.squeeze().float().cpu().clamp_(0, 1).numpy()
+            self._check_range()
             output_alpha = np.transpose(output_alpha[[2, 1, 0], :, :], (1, 2, 0))
             output_alpha = _bgr2gray(output_alpha)
             output_img = np.concatenate([output_img, output_alpha[:, :, None]], axis=2)
@@ -380,6 +391,7 @@ class RealESRGANer:
             # /255, BGR->RGB, network, clamp, RGB->BGR, x255, round -- all inside the HIP path
             x = torch.from_numpy(np.ascontiguousarray(img)).to(self.device)
             output = self.model.forward_u8(x, flip_rgb=True, round_nearest=True).cpu().numpy()
+            self._check_range(0)
             img_mode = "RGB"
         elif self._u8_on_device_ok(img):
             output = self._enhance_u8_on_device(img)

@@ -79,8 +79,10 @@ class RRDBNet(nn.Module):
     Args mirror upstream: num_in_ch, num_out_ch, scale=4, num_feat=64, num_block=23, num_grow_ch=32.
     Extra keyword ``compute_dtype``:
       "f32" (default; the reference's half=False)  f32 in / out / accumulation; every conv operand is carried
-                      as an exact-sum pair of halves and each product is three f16 MFMAs (conv3x3_f16x2.hip);
-                      whole-network max abs error vs an f64 evaluation 3e-6 (torch CPU f32: 1e-6)
+                      as a pair of halves (x = hi + lo 2^-11) and each product is three f16 MFMAs (conv3x3_f16x2.hip);
+                      whole-network max abs error vs an f64 evaluation 3e-6 (torch CPU f32: 1e-6).  Values beyond
+                      +-65504 or non-finite do not fit: weights are refused at upload, activations turn the output
+                      into NaN and raise NesrRangeError at the next check_range()/check_status()
       "f32-winograd"  f32 matrix cores, Winograd F(2x2,3x3) for the feature-map convs (error 2e-6)
       "f32-direct"    f32 matrix cores, direct implicit GEMM: bitwise a k-ordered fmaf chain
       "bf16"          bf16 storage and MFMA, f32 accumulation (upstream's half=True is fp16)
@@ -97,6 +99,8 @@ class RRDBNet(nn.Module):
         self.num_grow_ch = num_grow_ch
         self.compute_dtype = compute_dtype
         self._build_params()
+        self.calls = 0            # forward evaluations so far (callers assert on it: the reference's exception ladders
+                                  # turn a dead backend into a silent bicubic resize, nesr/nesr.py:815-843)
         self._ctx = None          # (ctypes handle, device index, dtype code): slot 0
         self._dirty = True        # parameters changed since the last upload
         self._extra = {}          # slot -> (handle, device index, dtype code): replicas for concurrent streams
@@ -127,6 +131,14 @@ class RRDBNet(nn.Module):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         self._dirty = True
         return out
+
+    def half(self):
+        """Upstream's fp16 switch (RealESRGANer(half=True) calls model.half()).  Here it selects the bf16 MFMA
+        kernels; the parameters stay float32, so the bf16 weights are rounded once from the checkpoint's values
+        (not float32 -> fp16 -> bf16)."""
+        self.compute_dtype = "bf16"
+        self._dirty = True
+        return self
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -235,6 +247,7 @@ class RRDBNet(nn.Module):
         if h % u or w % u:
             raise AssertionError(f"hh({h}) and hw({w}) must be divisible by {u}")  # upstream pixel_unshuffle asserts
         s = self.out_scale()
+        self.calls += 1
         with torch.cuda.device(xf.device):
             ctx = self._context(xf.device, slot)
             y = torch.empty((n, self.num_out_ch, h * s, w * s), dtype=torch.float32, device=xf.device)
@@ -255,6 +268,7 @@ class RRDBNet(nn.Module):
         x = img_hwc_u8.contiguous()
         h, w, _ = x.shape
         s = self.out_scale()
+        self.calls += 1
         with torch.cuda.device(x.device):
             ctx = self._context(x.device, slot)
             y = torch.empty((h * s, w * s, 3), dtype=torch.uint8, device=x.device)
@@ -370,6 +384,22 @@ class RRDBNet(nn.Module):
         """Synchronises the device and raises if asynchronous work of this model failed."""
         if self._ctx is not None:
             _lib.check(_lib.load().nesr_check_status(self._ctx[0]), "nesr_check_status")
+        self.check_range()
+
+    def check_range(self, slot=None):
+        """Raises NesrRangeError if a forward enqueued so far (on torch's current stream) met an input or activation
+        the f16-pair fp32 form cannot carry (non-finite or beyond +-65504): its float output is NaN and an 8-bit
+        output is invalid.  Waits for the current stream only; a no-op for the other compute dtypes.  The wrappers
+        call it after every device-to-host copy (the reference would have returned NaN pixels, nesr/nesr.py:891-898)."""
+        handles = ([self._ctx] if self._ctx is not None else []) + list(self._extra.values()) if slot is None else \
+                  [self._ctx if slot == 0 else self._extra.get(slot)]
+        lib = _lib.load()
+        for h in handles:
+            if h is None or h[2] != _lib.DTYPE_F32_SPLIT:
+                continue
+            dev = torch.device("cuda", h[1])
+            with torch.cuda.device(dev):
+                _lib.check(lib.nesr_check_range(h[0], ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "nesr_check_range")
 
     def kernel_time(self):
         """(total ms, launches, algorithmic flops) of the dense-block convs since the last call."""
@@ -402,7 +432,8 @@ def conv3x3(x, weight, bias, lrelu=False, upsample=False, dtype="f32"):
     index = x.device.index if x.device.index is not None else torch.cuda.current_device()
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        code = {"bf16": _lib.DTYPE_BF16, "f32-winograd": _lib.DTYPE_F32_WINOGRAD, "f32": _lib.DTYPE_F32, "f32-split": _lib.DTYPE_F32_SPLIT,
+        # "f32" is what RRDBNet(compute_dtype="f32") runs: the f16-pair kernel
+        code = {"bf16": _lib.DTYPE_BF16, "f32-winograd": _lib.DTYPE_F32_WINOGRAD, "f32": _lib.DTYPE_F32_SPLIT, "f32-split": _lib.DTYPE_F32_SPLIT,
                 "f32-direct": _lib.DTYPE_F32}[dtype]
         _lib.check(lib.nesr_conv3x3(index, code,
                                     ctypes.c_void_p(x.data_ptr()), n, cin, h, w, ctypes.c_void_p(wt.data_ptr()),

@@ -138,3 +138,45 @@ def process_with_tiling(processor, image, tile_size, padding, upscale_factor):
                 region = lanczos4_resize_u8(region, oh, ow)
             output[oy0:oy1, ox0:ox1] = region
     return output
+
+
+def apply_esrgan(model, image, config=None, device_kind="cuda", large_mp=16, trace=None):
+    """nesr.py:754-813 (the dispatch; the exception ladder :815-843 is not restated: the oracle's network does not fail).
+    `large_mp` is the literal 16 of nesr.py:787."""
+    cfg = {"enable_tiling": True, "force_3channel": False, "max_tile_size": 512, "upscale_factor": 2.0}
+    cfg.update(config or {})
+    h, w, _ = image.shape
+    image_megapixels = (h * w) / (1024 * 1024)                                   # nesr.py:762
+    use_tiling = False
+    if cfg["enable_tiling"]:                                                       # nesr.py:766-776
+        if device_kind == "cpu":
+            threshold = cfg.get("cpu_megapixel_threshold", 2)
+        elif device_kind == "mps":
+            threshold = cfg.get("mps_megapixel_threshold", 4)
+        else:
+            threshold = cfg.get("cuda_megapixel_threshold", 8)
+        use_tiling = image_megapixels > threshold
+    use_3channel = cfg["force_3channel"]                                           # nesr.py:779
+    if device_kind == "mps" and image_megapixels > 1:                             # nesr.py:782-784
+        use_3channel = True
+    if image_megapixels > large_mp:                                                # nesr.py:787-790
+        use_tiling = True
+        use_3channel = True
+    proc = (lambda t: apply_3channel(model, np.ascontiguousarray(t))) if use_3channel else \
+           (lambda t: apply_12channel(model, np.ascontiguousarray(t)))
+    if trace is not None:
+        trace.append({"in_shape": (h, w), "tiled": use_tiling, "three_channel": use_3channel})
+    if use_tiling:                                                                 # nesr.py:797-807
+        return process_with_tiling(proc, image, cfg["max_tile_size"], 16, cfg["upscale_factor"])
+    return proc(image)                                                             # nesr.py:810-813
+
+
+def enhance_iterations(model, image, config=None, device_kind="cuda", large_mp=16, trace=None):
+    """nesr.py:516-633 with use_diffusion=False, segment_enhancement=False and the cv2 pre/post filters off:
+    per iteration current = _ensemble_results([_apply_esrgan(current)]) = _apply_esrgan(current) (nesr.py:1035-1036)."""
+    cfg = {"iterations": 3, "upscale_factor": 2.0}
+    cfg.update(config or {})
+    current = image
+    for _ in range(int(cfg["iterations"])):
+        current = apply_esrgan(model, current, cfg, device_kind, large_mp, trace)
+    return current

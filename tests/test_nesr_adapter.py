@@ -101,6 +101,49 @@ def test_dispatcher_thresholds():
     assert out.shape == (128, 128, 3) and len(calls) == 4                       # tiled: canvas from upscale_factor 2
 
 
+def test_iteration_driver_cpu_vs_oracle():
+    """nesr.py:516-633 around the ESRGAN stage: three iterations that take the three routes of _apply_esrgan
+    (untiled 12-channel -> tiled 12-channel -> forced tiling + 3-channel).  The adapter's host logic with a torch
+    CPU network injected, against the numpy oracle with the same network."""
+    model, _ = _ref_model()
+    up = _Up(model, "cpu")
+    img = synthetic_frame(20, 24, seed=9)
+    cfg = {"iterations": 3, "upscale_factor": 2.0, "max_tile_size": 48, "cuda_megapixel_threshold": 0.005}
+    large = 0.02
+    trace, otrace = [], []
+    got = A.enhance_iterations(up, img, cfg, "cuda", trace=trace, large_mp=large)
+    want = O.enhance_iterations(model, img, cfg, "cuda", large_mp=large, trace=otrace)
+    assert got.shape == want.shape == (320, 384, 3)
+    assert [(t["tiled"], t["three_channel"]) for t in trace] == [(t["tiled"], t["three_channel"]) for t in otrace] == \
+        [(False, False), (True, False), (True, True)]
+    assert [t["in_shape"] for t in trace] == [(20, 24), (80, 96), (160, 192)]
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 3 and (d > 0).mean() < 0.02      # float32 Lanczos in torch vs numpy: rounding ties, passed on
+
+
+@pytest.mark.gpu
+def test_three_channel_route_on_gpu_vs_oracle(cuda_device):
+    """_apply_esrgan_3channel (nesr.py:905-945) on the HIP engine, and the forced branch of nesr.py:787-790
+    (beyond the large-image literal: tiling + 3-channel) through the dispatcher."""
+    from neural_enhanced_super_resolution_amd import RealESRGANer, RRDBNet
+    model, sd = _ref_model(num_block=2, seed=6)
+    up = RealESRGANer(scale=2, model_path={"params_ema": sd}, model=RRDBNet(12, 3, num_block=2), tile=0, tile_pad=0,
+                      pre_pad=0, half=False, device="cuda")
+    img = synthetic_frame(48, 72, seed=7)
+    got = A.apply_esrgan_3channel(up, img)
+    want = O.apply_3channel(model, img)
+    assert got.shape == (192, 288, 3)
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3
+    calls = up.model.calls
+    trace = []
+    got = A.apply_esrgan(up, img, {"max_tile_size": 32}, trace=trace, large_mp=0.002)
+    want = O.apply_esrgan(model, img, {"max_tile_size": 32}, large_mp=0.002)
+    assert trace[0]["tiled"] and trace[0]["three_channel"] and up.model.calls - calls == 6
+    assert got.shape == want.shape == (96, 144, 3)
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 2
+
+
 @pytest.mark.gpu
 def test_adapter_on_gpu_vs_oracle(cuda_device):
     from neural_enhanced_super_resolution_amd import RealESRGANer, RRDBNet
