@@ -189,7 +189,10 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : 2)
     const unsigned lds_base = (unsigned)(size_t)(lds_char*)(smem);
     unsigned voff[IN_ROUNDS];
     unsigned okmask = 0;
-    const char* in_img = static_cast<const char*>(a.in) + (size_t)n * a.in_h * a.in_w * 64;
+    // scalar base = image n, first stored row this tile reads; the per-lane offsets below are relative to it and stay
+    // below (tile rows + 2) * in_w * 64 bytes, so frames of any size address correctly (64-bit base, 32-bit offsets)
+    const int row0 = (y0 > 0 ? y0 - 1 : 0) >> a.up;
+    const char* in_img = static_cast<const char*>(a.in) + ((size_t)n * a.in_h + row0) * a.in_w * 64;
     const long long in_cstride = a.in_map.chunk * 2;   // bytes between K-chunks
     const char* wbase = static_cast<const char*>(a.w) + (size_t)cg * W_BYTES;
     const long long w_cstride = (long long)CG * W_BYTES;
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : 2)
             const int Y = y0 - 1 + py, X = x0 - 1 + px;
             const bool has = k < IN_ITEMS;
             const bool ok = has && Y >= 0 && Y < a.h && X >= 0 && X < a.w_;
-            voff[i] = ((unsigned)(Y >> a.up) * (unsigned)a.in_w + (unsigned)(X >> a.up)) * 64u + sg * 16;
+            voff[i] = ((unsigned)((Y >> a.up) - row0) * (unsigned)a.in_w + (unsigned)(X >> a.up)) * 64u + sg * 16;
             okmask |= ok ? (1u << i) : 0u;
             dma_round(0, 0, W_ROUNDS + i);
             if (has && !ok) {
@@ -519,7 +522,7 @@ void pack_weights_f16x2(const float* oihw, int cout, int cin, int cin_p, int cou
 
 hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s) {
     if (a.cin % 16 || (a.coutp != 32 && a.coutp != 64)) return hipErrorInvalidValue;
-    if ((long long)a.in_h * a.in_w >= (1ll << 26)) return hipErrorInvalidValue;   // 32-bit byte offsets inside one image chunk
+    if ((long long)a.in_w * 64 * 12 >= (1ll << 32)) return hipErrorInvalidValue;   // 32-bit byte offsets inside one tile's rows
     if (a.in_map.pix != 32 || (a.out && (a.out_map.pix % 32 || a.out_coff % 16))) return hipErrorInvalidValue;
     if ((a.out_nchw || a.out_u8) && (a.coutp != 32 || a.cout_real < 1 || a.cout_real > 4)) return hipErrorInvalidValue;
     // 8x32-px tiles.  Launches that give a CU at most one workgroup (a 512x512 frame's 32-channel layers): four

@@ -217,15 +217,19 @@ def apply_esrgan(upscaler, image_rgb, config=None, device_kind="cuda", as_numpy=
         use_tiling, use_3ch = True, True
     model = upscaler.model
     calls0 = getattr(model, "calls", None)
-    one = (lambda t: apply_esrgan_3channel(upscaler, t, as_numpy=False)) if use_3ch else \
-          (lambda t: apply_esrgan_12channel(upscaler, t, as_numpy=False))
+    net_px = [0]
+
+    def one(t):
+        net_px[0] += int(t.shape[0]) * int(t.shape[1])
+        return apply_esrgan_3channel(upscaler, t, as_numpy=False) if use_3ch else apply_esrgan_12channel(upscaler, t, as_numpy=False)
+
     if use_tiling:
         out = process_with_tiling(one, image_rgb, cfg["max_tile_size"], 16, cfg["upscale_factor"], upscaler.device, as_numpy=False)
     else:
         out = one(image_rgb)
     if trace is not None:
         trace.append({"in_shape": (h, w), "out_shape": tuple(out.shape[:2]), "tiled": bool(use_tiling), "three_channel": bool(use_3ch),
-                      "model_calls": None if calls0 is None else model.calls - calls0})
+                      "model_calls": None if calls0 is None else model.calls - calls0, "net_input_px": net_px[0]})
     if as_numpy:
         return _to_host(upscaler, out)
     return out
