@@ -131,6 +131,46 @@ __device__ __forceinline__ f32x4 ld4_split(const uint16_t* p) {
                  fmaf((float)l[2], LO_INV, (float)h[2]), fmaf((float)l[3], LO_INV, (float)h[3])};
 }
 
+
+// ---- whole-line feature-map access for the 16x16x32 epilogue.  After the cout exchange lane (pixel j16, k-group g4)
+// holds 8 consecutive couts of ONE pixel: base 0 / 16 / 8 / 24 for g4 = 0 / 1 / 2 / 3, i.e. piece g4>>1 (8 channels)
+// of chunk X (g4 even) or X + 1 (g4 odd), as a hi and a lo 16-byte piece.  Stored like that, a wave instruction
+// would write 16-byte fragments of 64 different 64-byte slots (measured: ~4.6 us per epilogue, the stores crawl
+// through the address coalescer).  One v_permlane16_swap per register (odd rows of `hi` <-> even rows of `lo`)
+// regroups the pieces by CHUNK: afterwards `hi` holds, for every lane, a piece of chunk X -- piece index
+// 2 (g4 & 1) + (g4 >> 1) of the pixel's 64-byte slot [hi 0-7 | hi 8-15 | lo 0-7 | lo 8-15] -- and `lo` the same piece
+// of chunk X + 1: two store instructions of 16 pixels x 64 bytes = 1 KiB of whole lines each.  The swap is its own
+// inverse, so residuals are loaded the same way.  All 64 lanes must execute these (no divergence around them).
+__device__ __forceinline__ void regroup_pairs(uint4& hi, uint4& lo) {
+    auto s0 = __builtin_amdgcn_permlane16_swap(hi.x, lo.x, false, false);
+    auto s1 = __builtin_amdgcn_permlane16_swap(hi.y, lo.y, false, false);
+    auto s2 = __builtin_amdgcn_permlane16_swap(hi.z, lo.z, false, false);
+    auto s3 = __builtin_amdgcn_permlane16_swap(hi.w, lo.w, false, false);
+    hi = uint4{s0[0], s1[0], s2[0], s3[0]};
+    lo = uint4{s0[1], s1[1], s2[1], s3[1]};
+}
+// v0, v1 = this lane's 8 couts -> split, regrouped: `cx` goes to chunk X, `cx1` to chunk X + 1 (at piece offset)
+__device__ __forceinline__ void split_regroup(f32x4 v0, f32x4 v1, uint4& cx, uint4& cx1, bool& bad) {
+    uint2 h0, l0, h1, l1;
+    split4(v0, h0, l0, bad);
+    split4(v1, h1, l1, bad);
+    cx = uint4{h0.x, h0.y, h1.x, h1.y};
+    cx1 = uint4{l0.x, l0.y, l1.x, l1.y};
+    regroup_pairs(cx, cx1);
+}
+// the inverse for residuals: p = the pixel's slot in chunk X (2-byte units), piece8 = this lane's piece offset
+__device__ __forceinline__ void load_regrouped(const uint16_t* p, long long chunk_el, f32x4& q0, f32x4& q1) {
+    uint4 cx = *reinterpret_cast<const uint4*>(p);
+    uint4 cx1 = *reinterpret_cast<const uint4*>(p + chunk_el);
+    regroup_pairs(cx, cx1);      // -> own hi, own lo
+    const f16x8 h = __builtin_bit_cast(f16x8, cx), l = __builtin_bit_cast(f16x8, cx1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        q0[i] = fmaf((float)l[i], LO_INV, (float)h[i]);
+        q1[i] = fmaf((float)l[4 + i], LO_INV, (float)h[4 + i]);
+    }
+}
+
 #ifndef NESR_ABL
 #define NESR_ABL 0   // timing ablations: 1 empty kernel, 2 stop after the prologue, 4 no epilogue, 8 no MFMA, 16 no K-loop DMA, 64 cycle stamps, 512 no per-chunk barrier
 #endif
@@ -275,6 +315,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : 2)
     // this lane's 8 output channels after the epilogue's permlane16 exchange, and their bias (fetched now: the
     // latency hides under the K loop)
     const int cb16 = 32 * cg + (g4 & 1) * 16 + (g4 >> 1) * 8;
+    const int piece8 = ((g4 & 1) * 2 + (g4 >> 1)) * 8;    // this lane's 16-byte piece of a 64-byte slot after regroup_pairs (2-byte units)
     const f32x4 bz0 = *reinterpret_cast<const f32x4*>(a.bias + cb16), bz1 = *reinterpret_cast<const f32x4*>(a.bias + cb16 + 4);
 
     const int nchunks = a.cin / 16;
@@ -401,7 +442,6 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : 2)
             const int Y = y0 + RW * wave + r, X = x0 + 16 * nh + j16;
             const bool valid = X < a.w_ && Y < a.h;
             const size_t pix = ((size_t)n * a.h + (Y < a.h ? Y : 0)) * a.w_ + (X < a.w_ ? X : 0);
-            auto at = [&](const Map& mp, int c) -> size_t { return (size_t)(c >> 4) * mp.chunk + pix * mp.pix + (c & 15); };
             f32x4 v0, v1;   // couts cb .. cb+3, cb+4 .. cb+7
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -417,33 +457,37 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : 2)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { v0[i] = v0[i] > 0.f ? v0[i] : v0[i] * 0.2f; v1[i] = v1[i] > 0.f ? v1[i] : v1[i] * 0.2f; }
             }
+            // slot of this pixel in chunk X = (coff + 32 cg) / 16 of a map, at this lane's piece
+            auto slot = [&](const Map& mp, int coff) -> size_t { return (size_t)((coff + 32 * cg) >> 4) * mp.chunk + pix * mp.pix + piece8; };
             if (res1) {
-                const f32x4 q0 = ld4_split(res1 + at(a.res1_map, cb)), q1 = ld4_split(res1 + at(a.res1_map, cb + 4));
+                f32x4 q0, q1;
+                load_regrouped(res1 + slot(a.res1_map, 0), a.res1_map.chunk, q0, q1);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s1), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s1), q1[i]); }
             }
             if (res2) {
-                const f32x4 q0 = ld4_split(res2 + at(a.res2_map, cb)), q1 = ld4_split(res2 + at(a.res2_map, cb + 4));
+                f32x4 q0, q1;
+                load_regrouped(res2 + slot(a.res2_map, 0), a.res2_map.chunk, q0, q1);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s2), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s2), q1[i]); }
             }
-            if (!valid) continue;
             if (out || out2) {
-                uint2 h0, l0, h1, l1;
-                split4(v0, h0, l0, bad);
-                split4(v1, h1, l1, bad);
-                const uint4 whi = uint4{h0.x, h0.y, h1.x, h1.y}, wlo = uint4{l0.x, l0.y, l1.x, l1.y};
-                if (out) {
-                    uint16_t* p = out + at(a.out_map, a.out_coff + cb);
-                    store16(p, whi);
-                    store16(p + 16, wlo);
+                uint4 cx, cx1;
+                bool bad_here = false;
+                split_regroup(v0, v1, cx, cx1, bad_here);
+                bad |= bad_here && valid;
+                if (valid && out) {
+                    uint16_t* p = out + slot(a.out_map, a.out_coff);
+                    store16(p, cx);
+                    store16(p + a.out_map.chunk, cx1);
                 }
-                if (out2) {
-                    uint16_t* p = out2 + at(a.out2_map, cb);
-                    store16(p, whi);
-                    store16(p + 16, wlo);
+                if (valid && out2) {
+                    uint16_t* p = out2 + slot(a.out2_map, 0);
+                    store16(p, cx);
+                    store16(p + a.out2_map.chunk, cx1);
                 }
             }
+            if (!valid) continue;
             if (a.cout_real > 0 && cb == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -465,6 +509,400 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : 2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(4);
 #endif
+}
+
+// ======================================================================================================
+// One residual dense block per launch (frames whose 8x32-pixel tiles fit the CUs, e.g. 512x512 x2plus: 256 tiles).
+//
+// A per-layer launch of such a frame is one round of 256-512 workgroups that all wait for their first bytes at the
+// same time, all compute, all store: ~6.6 us of every ~20 us launch is not matrix work.  Here
+// a workgroup keeps its tile through conv1..conv5 of the block: 52 K-chunk steps (4 + 6 + 8 + 10 + 2 x 12) in ONE
+// software pipeline -- the DMA waves run one step ahead straight across the layer boundaries, the LDS-DMA plan is
+// computed once, and a layer's stores drain while the next layer's first chunks are already being multiplied.
+//
+// The only thing a layer needs from other workgroups is the 1-pixel halo of the 32 channels the previous layer has
+// just produced -- and in a dense block those are the LAST two of its 6..12 input chunks.  So the wait is placed there:
+// the DMA waves poll the neighbours' progress words (one per tile: x1..x4 published) just before they fetch those two
+// chunks, several microseconds after the neighbours stored them.  Protocol (MI355X_MICROARCH.md, inter-workgroup
+// visibility): producer = write-through (sc1) 16-byte stores, every storing wave's s_waitcnt vmcnt(0), the
+// workgroup barrier, one lane's relaxed agent-scope store of the progress word; consumer = relaxed agent-scope
+// (sc1) polls by the wave that then issues the loads, loads that bypass L1 (sc1).  Nothing is read before it has
+// been written inside one launch and a kernel boundary invalidates L1/L2, so no line can be stale.  Every tile has its
+// own resident workgroup (grid <= CUs, one workgroup per CU): waits are bounded and set an abort word instead of hanging.
+struct RdbArgs {
+    const void* cur;         // the block's 192-channel buffer: x0 read, x1..x4 written then read
+    long long chunk_bytes;   // bytes between its 16-channel chunks (pixels * 64)
+    void* out;               // conv5's destination: the x0 slice of the next block's buffer (same geometry)
+    const void* res2;        // second residual (the RRDB's input, x0 slice of its first buffer) or null
+    float s1, s2;
+    const void* w[5];        // packed weights of conv1..conv5 (pack_weights_f16x2)
+    const float* bias[5];
+    int n, h, w_;
+    unsigned* progress;      // [tiles] epoch + layers published
+    unsigned epoch;          // progress == epoch + j  <=>  x_j of this launch is visible
+    unsigned* abort_flag;
+    unsigned* status;        // sticky range word (ConvArgs::status)
+};
+
+__device__ __forceinline__ void glds16_s_sc1(const char* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2 sc1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+__device__ __forceinline__ void store16_wt(uint16_t* p, uint4 v) {   // write-through: visible device-wide once vmcnt retires it
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(f32x4, v)) : "memory");
+}
+
+#ifndef NESR_RDB_PUB_DELAY
+#define NESR_RDB_PUB_DELAY 2   // steps between a layer's epilogue and the publication of its progress word
+#endif
+#ifndef NESR_RDB_ABL
+#define NESR_RDB_ABL 0   // timing ablations (WRONG results): 1 no neighbour polling, 2 plain activation loads, 4 plain x1..x4 stores, 8 no MFMA, 16 no epilogue
+#endif
+
+// s_waitcnt vmcnt(k) for a wave-uniform run-time k (the count is an immediate)
+__device__ __forceinline__ void wait_vmcnt_le(int k) {
+    switch (k) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    }
+}
+
+constexpr int RSLOTS = 3;   // ring slots of the fused kernel: the DMA waves run two steps ahead
+
+__global__ __launch_bounds__(64 * (WAVES + 4), 2) void rdb_f16x2_kernel(RdbArgs a) {
+    typedef Geo<4> G;
+    constexpr int THREADS = G::THREADS, TH = G::TH;
+    constexpr int IN_ITEMS = G::IN_ITEMS, IN_ROUNDS = G::IN_ROUNDS, IN_BYTES = G::IN_BYTES;
+    constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
+    constexpr int WRING = RSLOTS * IN_BYTES;       // LDS: [input ring: RSLOTS x IN_BYTES][weight ring: RSLOTS x W_BYTES]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool is_dma = wave_all >= WAVES;
+    const bool is_cmp = !is_dma;
+    const int wave = is_cmp ? wave_all : wave_all - WAVES;
+    const int tid = wave * 64 + lane;
+
+    const int tiles_x = (a.w_ + TW - 1) / TW;
+    const int tiles_y = (a.h + TH - 1) / TH;
+    const int total = tiles_x * tiles_y * a.n;
+    int tile;
+    {
+        const int bid = blockIdx.x, q = total >> 3, r = total & 7, xcd = bid & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int n = tile / (tiles_x * tiles_y);
+    const int t2 = tile - n * tiles_x * tiles_y;
+    const int ty = t2 / tiles_x, tx = t2 - ty * tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    // ---- DMA role: the plan (once per block) and the neighbours' progress words
+    const unsigned lds_base = (unsigned)(size_t)(lds_char*)(smem);
+    unsigned voff[IN_ROUNDS];
+    unsigned okmask = 0;       // per lane: rounds in which this lane has an in-image item
+    unsigned wavemask = 0;     // wave-uniform: rounds in which any lane of the wave has one (= instructions issued)
+    const int row0 = y0 > 0 ? y0 - 1 : 0;
+    const char* in_img = static_cast<const char*>(a.cur) + ((size_t)n * a.h + row0) * a.w_ * 64;
+    const unsigned* watch = nullptr;    // lanes 0..8: progress word of tile (ty + i/3 - 1, tx + i%3 - 1), if it exists
+    int kdma = 0;                       // LDS-DMA instructions this wave issues per step (vmcnt counts wave instructions)
+    if (is_dma) {
+        if (lane < 9) {
+            const int ny = ty + lane / 3 - 1, nx = tx + lane % 3 - 1;
+            if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) watch = a.progress + (n * tiles_y + ny) * tiles_x + nx;
+        }
+        int p = tid >> 2;
+        int py = p / PW, px = p - py * PW;
+        const int sl = tid & 3;
+#pragma unroll
+        for (int i = 0; i < IN_ROUNDS; ++i) {
+            const int k = tid + THREADS * i;
+            const int sg = sl ^ (((px >> 2) & 1) << 1);
+            const int Y = y0 - 1 + py, X = x0 - 1 + px;
+            const bool has = k < IN_ITEMS;
+            const bool ok = has && Y >= 0 && Y < a.h && X >= 0 && X < a.w_;
+            voff[i] = ((unsigned)(Y - row0) * (unsigned)a.w_ + (unsigned)X) * 64u + sg * 16;
+            okmask |= ok ? (1u << i) : 0u;
+            if (__builtin_amdgcn_ballot_w64(ok) != 0ull) { wavemask |= 1u << i; ++kdma; }
+            if (has && !ok) {
+#pragma unroll
+                for (int sl2 = 0; sl2 < RSLOTS; ++sl2) *reinterpret_cast<f32x4*>(smem + sl2 * IN_BYTES + k * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            px += (THREADS / 4) % PW;
+            py += (THREADS / 4) / PW;
+            if (px >= PW) { px -= PW; py += 1; }
+        }
+#pragma unroll
+        for (int j = 0; j < W_ROUNDS; ++j) kdma += (wave * 64 + THREADS * j) < W_ITEMS ? 1 : 0;
+    }
+    unsigned seen = 0;     // DMA waves: layers of this launch known to be published by all nine tiles
+    // DMAs of one step: weight slab of (layer l, cout group cg, chunk c), then input chunk c -- after the nine tiles
+    // have published the layer that produced it (chunks 4.. hold x1..: chunk c belongs to x_((c-4)/2+1)).
+    // Exactly kdma wave instructions.
+    auto dma_step = [&](int l, int cg, int c, int slot) {
+        const int CG = l == 4 ? 2 : 1;
+        const char* wsrc = static_cast<const char*>(a.w[l]) + ((size_t)c * CG + cg) * W_BYTES;
+#pragma unroll
+        for (int j = 0; j < W_ROUNDS; ++j) {
+            const int k = tid + THREADS * j;
+            const unsigned dst = lds_base + WRING + slot * W_BYTES + j * (THREADS * 16) + wave * 1024;
+            if (k < W_ITEMS && !(NESR_RDB_ABL & 64)) glds16_s(wsrc, (unsigned)k * 16u, __builtin_amdgcn_readfirstlane(dst));
+        }
+        const unsigned need = c < 4 ? 0u : (unsigned)((c - 4) >> 1) + 1u;
+        if (need > seen && !(NESR_RDB_ABL & 1)) {
+            const unsigned target = a.epoch + need;
+            for (unsigned it = 0;; ++it) {
+                const unsigned v = watch ? __hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+                if (__builtin_amdgcn_ballot_w64((int)(v - target) < 0) == 0ull) break;
+                if (it > (1u << 22)) {     // ~1 s: a neighbour never arrived (workgroups not co-resident?)
+                    if (lane == 0) __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            seen = need;
+        }
+        const char* isrc = in_img + (long long)c * a.chunk_bytes;
+#pragma unroll
+        for (int i = 0; i < IN_ROUNDS; ++i) {
+            const unsigned dst = lds_base + slot * IN_BYTES + i * (THREADS * 16) + wave * 1024;
+            if (((wavemask >> i) & 1u) && !(NESR_RDB_ABL & 32)) {          // wave-uniform: the instruction count is the same every step
+                if ((okmask >> i) & 1u) {
+                    if (NESR_RDB_ABL & 2) glds16_s(isrc, voff[i], __builtin_amdgcn_readfirstlane(dst));
+                    else glds16_s_sc1(isrc, voff[i], __builtin_amdgcn_readfirstlane(dst));
+                }
+            }
+        }
+    };
+    // (layer, cout group, chunk) of the step after (l, cg, c); l == 5: past the end
+    auto advance = [](int& l, int& cg, int& c) {
+        const int nc = l == 4 ? 12 : 4 + 2 * l, ncg = l == 4 ? 2 : 1;
+        if (++c == nc) { c = 0; if (++cg == ncg) { cg = 0; ++l; } }
+    };
+    int fl = 0, fcg = 0, fc = 0;      // DMA waves: the next step to fetch
+    if (is_dma) {
+        dma_step(0, 0, 0, 0);
+        advance(fl, fcg, fc);
+        dma_step(fl, fcg, fc, 1);
+        advance(fl, fcg, fc);
+    }
+
+    // ---- MFMA role: operand addresses as in conv3x3_f16x2_kernel
+    const bool active = is_cmp && (y0 + RW * wave) < a.h;
+    const int j16 = lane & 15, g4 = lane >> 4, un = g4 >> 1, kh = g4 & 1;
+    int b16[5][2], a16[5];
+#pragma unroll
+    for (int st_ = 0; st_ < 5; ++st_) {
+        const int dy = st_ < 3 ? un : 2;
+        const int dx = st_ < 3 ? st_ : (st_ == 3 ? un : 2);
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+            const int col = 16 * nh + j16 + dx;
+            b16[st_][nh] = ((RW * wave + dy) * PW + col) * 64 + ((kh ^ (((col >> 2) & 1) << 1)) << 4);
+        }
+        a16[st_] = ((((dy * 3 + dx) * 2) * 2 + kh) * 32 + j16) * 16;
+    }
+    const int cbl = (g4 & 1) * 16 + (g4 >> 1) * 8;    // this lane's 8 output channels inside a 32-cout group after the permlane16 exchange
+    const int piece8 = ((g4 & 1) * 2 + (g4 >> 1)) * 8;  // its 16-byte piece of a 64-byte slot after regroup_pairs (2-byte units)
+    bool bad = false;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero padding is in LDS before the first barrier
+
+    int slot = 0, fill = 2;     // ring slot of the current step / of the step being fetched
+    int pub_level = 0, pub_wait = 0;
+    for (int l = 0; l < 5; ++l) {
+        const int nc = l == 4 ? 12 : 4 + 2 * l;
+        const int ncg = l == 4 ? 2 : 1;
+        for (int cg = 0; cg < ncg; ++cg) {
+            f32x4 acc16[RW][2][2][2];
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) acc16[r][nh][mt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 bz0 = f32x4{0.f, 0.f, 0.f, 0.f}, bz1 = bz0;
+            if (is_cmp) {
+                bz0 = *reinterpret_cast<const f32x4*>(a.bias[l] + 32 * cg + cbl);
+                bz1 = *reinterpret_cast<const f32x4*>(a.bias[l] + 32 * cg + cbl + 4);
+            }
+            for (int c = 0; c < nc; ++c) {
+                // DMA waves: this step's DMAs have landed (the next step's, issued one step ago, may still be in flight;
+                // none are after the last fetch).  MFMA waves: a layer's stores must have retired before its progress
+                // word goes out -- and they wait only then (they hold no other VM ops)
+                const bool publish_now = pub_wait > 0 && --pub_wait == 0;
+                if (is_dma) wait_vmcnt_le((NESR_RDB_ABL & 96) ? 0 : (fl < 5 || (l == 4 && cg == 1 && c < nc - 1) ? kdma : 0));
+                else if (publish_now) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (publish_now && wave_all == 0 && lane == 0)
+                    __hip_atomic_store(a.progress + tile, a.epoch + (unsigned)pub_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (is_dma && fl < 5) {      // two steps ahead, into the slot read one step ago
+                    dma_step(fl, fcg, fc, fill);
+                    advance(fl, fcg, fc);
+                }
+                if (active && !(NESR_RDB_ABL & 8)) {
+                    const char* st = smem + slot * IN_BYTES;
+                    const char* swb = smem + WRING + slot * W_BYTES;
+                    f32x4 Af[2][2][2];
+                    f32x4 Bf[2][RW][2][2];
+                    auto load_step = [&](int s_, int buf) {
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            if (s_ < 4) {
+                                Af[buf][mt][0] = *reinterpret_cast<const f32x4*>(swb + a16[s_] + mt * 256);
+                                Af[buf][mt][1] = *reinterpret_cast<const f32x4*>(swb + a16[s_] + mt * 256 + 1024);
+                            } else {
+                                f32x4 hi = *reinterpret_cast<const f32x4*>(swb + a16[4] + mt * 256);
+                                Af[buf][mt][1] = *reinterpret_cast<const f32x4*>(swb + a16[4] + mt * 256 + un * 1024);
+                                if (un) hi = f32x4{0.f, 0.f, 0.f, 0.f};
+                                Af[buf][mt][0] = hi;
+                            }
+                        }
+#pragma unroll
+                        for (int r = 0; r < RW; ++r)
+#pragma unroll
+                            for (int nh = 0; nh < 2; ++nh) {
+                                const int o0 = b16[s_][nh];
+                                const int o1 = s_ == 4 ? (b16[4][nh] ^ ((un ^ 1) << 5)) : (b16[s_][nh] ^ 32);
+                                Bf[buf][r][nh][0] = *reinterpret_cast<const f32x4*>(st + o0 + r * (PW * 64));
+                                Bf[buf][r][nh][1] = *reinterpret_cast<const f32x4*>(st + o1 + r * (PW * 64));
+                            }
+                    };
+                    load_step(0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s_ = 0; s_ < 5; ++s_) {
+                        const int buf = s_ & 1;
+                        if (s_ + 1 < 5) load_step(s_ + 1, buf ^ 1);
+                        if (NESR_RDB_ABL & 128) {      // LDS reads kept alive, no MFMA
+#pragma unroll
+                            for (int mt = 0; mt < 2; ++mt) { asm volatile("" ::"v"(Af[buf][mt][0]), "v"(Af[buf][mt][1])); }
+#pragma unroll
+                            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                                for (int nh = 0; nh < 2; ++nh) { asm volatile("" ::"v"(Bf[buf][r][nh][0]), "v"(Bf[buf][r][nh][1])); }
+                            continue;
+                        }
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            const f16x8 a0 = __builtin_bit_cast(f16x8, Af[buf][mt][0]), a1 = __builtin_bit_cast(f16x8, Af[buf][mt][1]);
+#pragma unroll
+                            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                                for (int nh = 0; nh < 2; ++nh) {
+                                    const f16x8 x0_ = __builtin_bit_cast(f16x8, Bf[buf][r][nh][0]), x1_ = __builtin_bit_cast(f16x8, Bf[buf][r][nh][1]);
+                                    if (s_ < 4) {
+                                        acc16[r][nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x1_, acc16[r][nh][mt][1], 0, 0, 0);
+                                        acc16[r][nh][mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x0_, acc16[r][nh][mt][0], 0, 0, 0);
+                                        acc16[r][nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x0_, acc16[r][nh][mt][1], 0, 0, 0);
+                                    } else {
+                                        acc16[r][nh][mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x0_, acc16[r][nh][mt][0], 0, 0, 0);
+                                        acc16[r][nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1_, acc16[r][nh][mt][1], 0, 0, 0);
+                                    }
+                                }
+                        }
+                        if (s_ + 1 < 5) {
+#pragma unroll
+                            for (int i = 0; i < 4 + 4 * RW; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                slot = slot == RSLOTS - 1 ? 0 : slot + 1;
+                fill = fill == RSLOTS - 1 ? 0 : fill + 1;
+            }
+            // ---- epilogue of (layer l, cout group cg): conv1..4 -> LeakyReLU into cur's channels 64 + 32 l;
+            // conv5 -> x5 * s1 + x0 (and * s2 + RRDB input) into `out`'s channels 32 cg
+            if (NESR_RDB_ABL & 16) {     // no epilogue; the accumulators stay live (no dead-code elimination of the K loop)
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) asm volatile("" ::"v"(acc16[r][nh][mt][0]), "v"(acc16[r][nh][mt][1]));
+            }
+            if (active && !(NESR_RDB_ABL & 16)) {
+                const uint16_t* cur16 = static_cast<const uint16_t*>(a.cur);
+                const uint16_t* res2 = static_cast<const uint16_t*>(a.res2);
+                uint16_t* dst16 = l == 4 ? static_cast<uint16_t*>(a.out) : const_cast<uint16_t*>(cur16);
+                const long long chunk_el = a.chunk_bytes >> 1;
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh) {
+                        const int Y = y0 + RW * wave + r, X = x0 + 16 * nh + j16;
+                        const bool valid = X < a.w_ && Y < a.h;
+                        const size_t pix = ((size_t)n * a.h + (Y < a.h ? Y : 0)) * a.w_ + (X < a.w_ ? X : 0);
+                        f32x4 v0, v1;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float e = fmaf(acc16[r][nh][0][1][i], LO_INV, acc16[r][nh][0][0][i]);
+                            const float o = fmaf(acc16[r][nh][1][1][i], LO_INV, acc16[r][nh][1][0][i]);
+                            const auto sw_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(e), __float_as_uint(o), false, false);
+                            v0[i] = __uint_as_float(sw_[0]);
+                            v1[i] = __uint_as_float(sw_[1]);
+                        }
+                        v0 += bz0;
+                        v1 += bz1;
+                        // slot of this pixel in chunk `ch` of a [chunks][pixels][64 B] buffer, at this lane's piece
+                        auto slot = [&](int ch) -> size_t { return (size_t)ch * chunk_el + pix * 32 + piece8; };
+                        if (l < 4) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { v0[i] = v0[i] > 0.f ? v0[i] : v0[i] * 0.2f; v1[i] = v1[i] > 0.f ? v1[i] : v1[i] * 0.2f; }
+                        } else {
+                            f32x4 q0, q1;
+                            load_regrouped(cur16 + slot(2 * cg), chunk_el, q0, q1);      // x0's couts 32 cg ..
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s1), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s1), q1[i]); }
+                            if (res2) {
+                                load_regrouped(res2 + slot(2 * cg), chunk_el, q0, q1);
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s2), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s2), q1[i]); }
+                            }
+                        }
+                        uint4 cx, cx1;
+                        bool bad_here = false;
+                        split_regroup(v0, v1, cx, cx1, bad_here);
+                        bad |= bad_here && valid;
+                        if (!valid) continue;
+                        uint16_t* pd = dst16 + slot(l == 4 ? 2 * cg : 4 + 2 * l);
+                        if (l < 4 && !(NESR_RDB_ABL & 4)) {
+                            store16_wt(pd, cx);
+                            store16_wt(pd + chunk_el, cx1);
+                        } else {
+                            *reinterpret_cast<uint4*>(pd) = cx;
+                            *reinterpret_cast<uint4*>(pd + chunk_el) = cx1;
+                        }
+                    }
+            }
+            if (l < 4) { pub_level = l + 1; pub_wait = NESR_RDB_PUB_DELAY; }
+        }
+    }
+    if (bad && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int DMAW>
@@ -518,6 +956,28 @@ void pack_weights_f16x2(const float* oihw, int cout, int cin, int cin_p, int cou
                 dst[ihi] = hi;
                 dst[ilo] = lo;
             }
+}
+
+int rdb_f16x2_tiles(int n, int h, int w) { return ((w + TW - 1) / TW) * ((h + 7) / 8) * n; }
+
+hipError_t launch_rdb_f16x2(const RdbLaunch& r, hipStream_t s) {
+    typedef Geo<4> G;
+    constexpr size_t shm = (size_t)RSLOTS * (G::IN_BYTES + (size_t)W_BYTES);
+    static unsigned long long attr_done = 0;
+    {
+        const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&rdb_f16x2_kernel), shm, attr_done);
+        if (e != hipSuccess) return e;
+    }
+    if ((long long)r.w_ * 64 * 12 >= (1ll << 32)) return hipErrorInvalidValue;
+    RdbArgs a;
+    a.cur = r.cur; a.chunk_bytes = r.chunk_bytes; a.out = r.out; a.res2 = r.res2; a.s1 = r.s1; a.s2 = r.s2;
+    for (int i = 0; i < 5; ++i) { a.w[i] = r.w[i]; a.bias[i] = r.bias[i]; }
+    a.n = r.n; a.h = r.h; a.w_ = r.w_;
+    a.progress = r.progress; a.epoch = r.epoch; a.abort_flag = r.abort_flag; a.status = r.status;
+    const int total = rdb_f16x2_tiles(r.n, r.h, r.w_);
+    if (total <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rdb_f16x2_kernel, dim3((unsigned)total), dim3(G::LAUNCH_THREADS), shm, s, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s) {

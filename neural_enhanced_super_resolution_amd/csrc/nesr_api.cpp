@@ -78,7 +78,11 @@ struct nesr_ctx {
     unsigned* last_sync = nullptr;   // abort word of the most recent persistent launch   // device copy of the trunk's layer table (persistent trunk kernel)
     int trunk_mode = 0;              // 0 auto, 1 per-layer launches, 2 persistent kernel
     int shared_device = 0;           // nesr_set_concurrent: other contexts run on the device at the same time
-    unsigned* d_status = nullptr;    // sticky range word of the f16-pair path (ConvArgs::status)
+    unsigned* d_status = nullptr;    // [0] sticky range word of the f16-pair path (ConvArgs::status), [1] abort word of the fused
+                                     // dense-block kernel, [64..] its per-tile progress words
+    unsigned rdb_epoch = 0;          // fused dense-block launches: progress values of a launch are epoch+1 .. epoch+4
+    int rdb_mode = -1;               // NESR_RDB_FUSE: -1 auto (fuse when every tile gets its own CU), 0 never
+    int cus = 256;
     unsigned* h_status = nullptr;    // pinned landing word of nesr_check_range
     FwState band;                    // the banded evaluation in progress (nesr_band_*)
     bool band_valid = false;
@@ -241,6 +245,36 @@ int fw_rdb(nesr_ctx* c, const FwState& F, int b, int r, hipStream_t s) {
     const int nf = c->nf, gc = c->gc;
     const double px = (double)F.N * F.h * F.w;
     char* cur = F.buf[r];
+    // small frames, f16-pair form: the whole dense block in one launch (rdb_f16x2_kernel).  Every tile needs its own
+    // resident workgroup, so the frame's tiles must fit the compute units and the device must be this context's
+    // (frames in flight on other streams would compete for the one workgroup slot per CU).
+    if (c->dtype == NESR_DTYPE_F32_SPLIT && c->rdb_mode != 0 && nf == 64 && gc == 32 && !c->shared_device) {
+        const int tiles = rdb_f16x2_tiles(F.N, F.h, F.w);
+        if (tiles <= c->cus && tiles <= 4096) {
+            RdbLaunch L;
+            std::memset(&L, 0, sizeof(L));
+            L.cur = cur;
+            L.chunk_bytes = F.m_t.chunk * 2;
+            L.out = r < 2 ? F.buf[r + 1] : F.buf[0];
+            L.res2 = r < 2 ? nullptr : F.buf[0];
+            L.s1 = 0.2f; L.s2 = 0.2f;
+            for (int k = 0; k < 5; ++k) {
+                const Layer& Ly = c->layers[layer_id(c, b, r, k)];
+                L.w[k] = Ly.d_w;
+                L.bias[k] = Ly.d_b;
+                if (c->timing) c->timed_flops += conv_flops(Ly, px);
+            }
+            L.n = F.N; L.h = F.h; L.w_ = F.w;
+            L.progress = c->d_status + 64;
+            c->rdb_epoch += 8;
+            L.epoch = c->rdb_epoch;
+            L.abort_flag = c->d_status + 1;
+            L.status = c->d_status;
+            HIP_TRY(launch_rdb_f16x2(L, s));
+            if (c->timing) c->timed_launches += 1;
+            return NESR_OK;
+        }
+    }
     for (int k = 0; k < 4; ++k) {
         const Layer& Ly = c->layers[layer_id(c, b, r, k)];
         ConvArgs a = base_args(c, Ly, F.N, F.h, F.w);
@@ -262,7 +296,7 @@ int fw_rdb(nesr_ctx* c, const FwState& F, int b, int r, hipStream_t s) {
     }
     a.out_map = F.m_t; a.out_coff = 0;
     HIP_TRY(launch_conv(c, a, s, &L5));
-    if (c->timing) c->timed_flops += conv_flops(L5, px);
+    if (c->timing) { c->timed_flops += conv_flops(L5, px); c->timed_launches += 5; }
     return NESR_OK;
 }
 
@@ -346,8 +380,10 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
         t.zeros = c->d_weights;
         HIP_TRY(launch_trunk_persist(t, c->kind() == 1, s));
         c->last_sync = sync;
-        if (c->timing)
+        if (c->timing) {
             for (int i = 0; i < c->nb * 15; ++i) c->timed_flops += conv_flops(c->layers[1 + i], (double)N * F.h * F.w);
+            c->timed_launches += 1;
+        }
     } else {
         for (int b = 0; b < c->nb; ++b)
             for (int r = 0; r < 3; ++r)
@@ -356,7 +392,6 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
     if (c->timing) {
         HIP_TRY(hipEventRecord(ev1, s));
         c->ev_pending.emplace_back(ev0, ev1);
-        c->timed_launches += (int64_t)c->nb * 15;
     }
     return fw_tail(c, F, y_f32, y_u8, flip, round_mode, s);
 }
@@ -388,8 +423,9 @@ int nesr_create(nesr_ctx** out, int device_id, int conv_first_in_ch, int unshuff
     HIP_TRY(hipSetDevice(device_id));
     unsigned* d_status = nullptr;
     unsigned* h_status = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_status, 256));
-    if (hipMemset(d_status, 0, 256) != hipSuccess || hipHostMalloc((void**)&h_status, 64, hipHostMallocDefault) != hipSuccess) {
+    constexpr size_t STATUS_BYTES = 256 + 4096 * 4;   // status words + progress words of up to 4096 tiles
+    HIP_TRY(hipMalloc((void**)&d_status, STATUS_BYTES));
+    if (hipMemset(d_status, 0, STATUS_BYTES) != hipSuccess || hipHostMalloc((void**)&h_status, 64, hipHostMallocDefault) != hipSuccess) {
         (void)hipFree(d_status);
         return fail(NESR_ERR_HIP, "allocating the context's status words failed");
     }
@@ -415,6 +451,8 @@ int nesr_create(nesr_ctx** out, int device_id, int conv_first_in_ch, int unshuff
     c->dtype = dtype;
     c->kgroup = (dtype == NESR_DTYPE_BF16 || dtype == NESR_DTYPE_F32_SPLIT) ? 16 : 8;
     if (const char* e = getenv("NESR_TRUNK")) c->trunk_mode = e[0] == 'l' ? 1 : (e[0] == 'p' ? 2 : 0);
+    if (const char* e = getenv("NESR_RDB_FUSE")) c->rdb_mode = atoi(e);
+    (void)hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device_id);
     auto add = [&](const std::string& name, int cin, int cout) {
         Layer L;
         L.name = name;
@@ -696,8 +734,16 @@ int nesr_check_range(nesr_ctx* c, void* stream) {
     if (c->dtype != NESR_DTYPE_F32_SPLIT) return NESR_OK;   // the other forms compute in formats with f32's range
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    HIP_TRY(hipMemcpyAsync(c->h_status, c->d_status, 4, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c->h_status, c->d_status, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    if (c->h_status[1]) {
+        HIP_TRY(hipMemsetAsync(c->d_status, 0, 8, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        c->h_status[0] = c->h_status[1] = 0;
+        return fail(NESR_ERR_HIP, "the fused dense-block kernel gave up waiting for a neighbouring tile (its workgroups were not all "
+                                  "resident: another persistent kernel shares the device?); the output of that forward is invalid. "
+                                  "NESR_RDB_FUSE=0 selects per-layer launches");
+    }
     if (*c->h_status) {
         HIP_TRY(hipMemsetAsync(c->d_status, 0, 4, s));   // reported once; the next forward starts clean
         HIP_TRY(hipStreamSynchronize(s));

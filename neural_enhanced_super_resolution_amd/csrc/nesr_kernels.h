@@ -100,6 +100,25 @@ hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s);
 size_t packed_weight_elems_f16x2(int cin_p, int coutp);   // in 2-byte units
 void pack_weights_f16x2(const float* oihw, int cout, int cin, int cin_p, int coutp, uint16_t* dst);
 
+// One residual dense block (conv1..conv5) per launch, f16-pair form, for frames whose 8x32-pixel tiles all get their
+// own resident workgroup (conv3x3_f16x2.hip, rdb_f16x2_kernel): tiles = rdb_f16x2_tiles(n, h, w) <= compute units.
+struct RdbLaunch {
+    const void* cur;          // the block's 192-channel buffer (f16-pair layout: [12 chunks][pixels][64 B])
+    long long chunk_bytes;
+    void* out;                // conv5 destination buffer (its channels 0..63)
+    const void* res2;         // RRDB input for the second residual, or null
+    float s1, s2;
+    const void* w[5];
+    const float* bias[5];
+    int n, h, w_;
+    unsigned* progress;       // [tiles] device words, monotonic across launches
+    unsigned epoch;           // strictly increasing by >= 8 per launch
+    unsigned* abort_flag;
+    unsigned* status;
+};
+int rdb_f16x2_tiles(int n, int h, int w);
+hipError_t launch_rdb_f16x2(const RdbLaunch& r, hipStream_t s);
+
 // Persistent trunk (conv3x3_mfma.hip): all dense-block convs of the 23 RRDBs in ONE cooperative
 // launch.  Workgroups keep their tiles from layer to layer and synchronise with their 8
 // neighbouring tiles only (per-tile progress counters, agent-scope release/acquire), instead of 345
