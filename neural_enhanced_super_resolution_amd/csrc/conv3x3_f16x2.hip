@@ -109,19 +109,29 @@ __device__ __forceinline__ void store16(uint16_t* p, uint4 v) {
 constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;   // lo is stored as f16((x - hi) * 2^11)
 constexpr float F16_MAX = 65504.f;
 
-// x -> (hi, scaled lo) halves of 4 values; `bad` collects "does not fit the pair" (|x| > 65504, NaN, Inf)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// two values -> packed (hi, hi), (lo, lo) halves.  hi = f16(x) (round to nearest even), lo = f16((x - hi) * 2^11):
+// x - hi is exact in f32 and so is the scaling, hence fma(hi, -2^11, x * 2^11) is that value bit for bit.  A value that
+// does not fit (|x| >= 65520, Inf, NaN) makes hi Inf / NaN: `badbits` collects the all-ones exponent fields (bit 15 of a
+// half after adding 0x0400 to its masked exponent), so nothing is clamped -- a non-finite half poisons the sums it enters,
+// the sticky flag is raised and conv_last writes NaN.
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& hi, unsigned& lo, unsigned& badbits) {
+    const f32x2 x = {x0, x1};
+    const f16x2 h = __builtin_convertvector(x, f16x2);                        // v_cvt_pk_f16_f32
+    const f32x2 hf = __builtin_convertvector(h, f32x2);
+    const f32x2 d = __builtin_elementwise_fma(hf, f32x2{-LO_SCALE, -LO_SCALE}, x * LO_SCALE);   // packed f32 mul / fma
+    const f16x2 l = __builtin_convertvector(d, f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+    badbits |= (hi & 0x7C007C00u) + 0x04000400u;
+}
+// x -> (hi, scaled lo) halves of 4 values; `bad` collects "does not fit the pair" (|x| >= 65520, NaN, Inf)
 __device__ __forceinline__ void split4(f32x4 v, uint2& hi, uint2& lo, bool& bad) {
-    f16x4 h, l;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        bad |= !(__builtin_fabsf(v[q]) <= F16_MAX);
-        const float x = fminf(fmaxf(v[q], -F16_MAX), F16_MAX);
-        const _Float16 hq = (_Float16)x;
-        h[q] = hq;
-        l[q] = (_Float16)((x - (float)hq) * LO_SCALE);
-    }
-    hi = __builtin_bit_cast(uint2, h);
-    lo = __builtin_bit_cast(uint2, l);
+    unsigned bits = 0;
+    split2(v[0], v[1], hi.x, lo.x, bits);
+    split2(v[2], v[3], hi.y, lo.y, bits);
+    bad |= (bits & 0x80008000u) != 0u;
 }
 // 4 consecutive channels of a split feature map: p -> hi halves, lo halves 16 elements on
 __device__ __forceinline__ f32x4 ld4_split(const uint16_t* p) {
@@ -455,7 +465,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : 2)
             v1 += bz1;
             if (a.lrelu) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { v0[i] = v0[i] > 0.f ? v0[i] : v0[i] * 0.2f; v1[i] = v1[i] > 0.f ? v1[i] : v1[i] * 0.2f; }
+                for (int i = 0; i < 4; ++i) { v0[i] = fmaxf(v0[i], v0[i] * 0.2f); v1[i] = fmaxf(v1[i], v1[i] * 0.2f); }   // LeakyReLU(0.2), same values as the select form
             }
             // slot of this pixel in chunk X = (coff + 32 cg) / 16 of a map, at this lane's piece
             auto slot = [&](const Map& mp, int coff) -> size_t { return (size_t)((coff + 32 * cg) >> 4) * mp.chunk + pix * mp.pix + piece8; };
@@ -586,21 +596,39 @@ __device__ __forceinline__ void wait_vmcnt_le(int k) {
     }
 }
 
-constexpr int RSLOTS = 3;   // ring slots of the fused kernel: the DMA waves run two steps ahead
+#if NESR_RDB_ABL & 256
+__device__ unsigned long long g_rdb_stamps[2][64][8];     // [role: MFMA wave 1 | DMA wave 0][step][event] of workgroup 77
+#define RSTAMP(role, step, ev) do { if (blockIdx.x == 77 && lane == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_rdb_stamps[role][step][ev] = t_; } } while (0)
+#else
+#define RSTAMP(role, step, ev) do { } while (0)
+#endif
 
-__global__ __launch_bounds__(64 * (WAVES + 4), 2) void rdb_f16x2_kernel(RdbArgs a) {
+constexpr int RSLOTS = 3;   // ring slots of the fused kernel: the DMA waves run two steps ahead
+constexpr int MW = 8;       // MFMA waves of the fused kernel: one tile row each, two per SIMD
+constexpr int DW = 4;       // DMA waves: LDS-DMA, neighbour polling, and the layers' epilogues
+constexpr int STAGE_BYTES = MW * 4096;   // accumulator hand-over MFMA waves -> DMA waves: [wave][pixel half, cout half][lane] 16 B
+
+// Roles.  MFMA waves (0..7): row w of the 8x32-pixel tile, 32 couts, nothing but LDS fragment reads and MFMAs; at the
+// end of a layer they add the cross-term accumulator into the main one and drop the 16 values per lane into the
+// staging area -- ~100 cycles -- and go on with the next layer, whose first steps are already in LDS.  DMA waves
+// (8..11): one step's LDS-DMAs two steps ahead (3-slot ring), and after a layer boundary the epilogue of the finished
+// layer from the staging area (bias, LeakyReLU / residuals, split, whole-line stores), which therefore runs beside the
+// next layer's MFMAs instead of in front of them; the ring's slack covers the ~1.5 us it takes.
+__global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a) {
     typedef Geo<4> G;
-    constexpr int THREADS = G::THREADS, TH = G::TH;
+    constexpr int THREADS = G::THREADS, TH = G::TH;      // THREADS = DMA lanes (256), TH = 8 rows
     constexpr int IN_ITEMS = G::IN_ITEMS, IN_ROUNDS = G::IN_ROUNDS, IN_BYTES = G::IN_BYTES;
     constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
-    constexpr int WRING = RSLOTS * IN_BYTES;       // LDS: [input ring: RSLOTS x IN_BYTES][weight ring: RSLOTS x W_BYTES]
+    constexpr int WRING = RSLOTS * IN_BYTES;             // LDS: [input ring][weight ring][staging]
+    constexpr int STAGE = RSLOTS * (IN_BYTES + W_BYTES);
+    static_assert(TH == MW, "one tile row per MFMA wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool is_dma = wave_all >= WAVES;
+    const bool is_dma = wave_all >= MW;
     const bool is_cmp = !is_dma;
-    const int wave = is_cmp ? wave_all : wave_all - WAVES;
+    const int wave = is_cmp ? wave_all : wave_all - MW;
     const int tid = wave * 64 + lane;
 
     const int tiles_x = (a.w_ + TW - 1) / TW;
@@ -616,99 +644,284 @@ __global__ __launch_bounds__(64 * (WAVES + 4), 2) void rdb_f16x2_kernel(RdbArgs 
     const int ty = t2 / tiles_x, tx = t2 - ty * tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;
 
-    // ---- DMA role: the plan (once per block) and the neighbours' progress words
-    const unsigned lds_base = (unsigned)(size_t)(lds_char*)(smem);
-    unsigned voff[IN_ROUNDS];
-    unsigned okmask = 0;       // per lane: rounds in which this lane has an in-image item
-    unsigned wavemask = 0;     // wave-uniform: rounds in which any lane of the wave has one (= instructions issued)
-    const int row0 = y0 > 0 ? y0 - 1 : 0;
-    const char* in_img = static_cast<const char*>(a.cur) + ((size_t)n * a.h + row0) * a.w_ * 64;
-    const unsigned* watch = nullptr;    // lanes 0..8: progress word of tile (ty + i/3 - 1, tx + i%3 - 1), if it exists
-    int kdma = 0;                       // LDS-DMA instructions this wave issues per step (vmcnt counts wave instructions)
-    if (is_dma) {
-        if (lane < 9) {
-            const int ny = ty + lane / 3 - 1, nx = tx + lane % 3 - 1;
-            if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) watch = a.progress + (n * tiles_y + ny) * tiles_x + nx;
-        }
-        int p = tid >> 2;
-        int py = p / PW, px = p - py * PW;
-        const int sl = tid & 3;
-#pragma unroll
-        for (int i = 0; i < IN_ROUNDS; ++i) {
-            const int k = tid + THREADS * i;
-            const int sg = sl ^ (((px >> 2) & 1) << 1);
-            const int Y = y0 - 1 + py, X = x0 - 1 + px;
-            const bool has = k < IN_ITEMS;
-            const bool ok = has && Y >= 0 && Y < a.h && X >= 0 && X < a.w_;
-            voff[i] = ((unsigned)(Y - row0) * (unsigned)a.w_ + (unsigned)X) * 64u + sg * 16;
-            okmask |= ok ? (1u << i) : 0u;
-            if (__builtin_amdgcn_ballot_w64(ok) != 0ull) { wavemask |= 1u << i; ++kdma; }
-            if (has && !ok) {
-#pragma unroll
-                for (int sl2 = 0; sl2 < RSLOTS; ++sl2) *reinterpret_cast<f32x4*>(smem + sl2 * IN_BYTES + k * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            px += (THREADS / 4) % PW;
-            py += (THREADS / 4) / PW;
-            if (px >= PW) { px -= PW; py += 1; }
-        }
-#pragma unroll
-        for (int j = 0; j < W_ROUNDS; ++j) kdma += (wave * 64 + THREADS * j) < W_ITEMS ? 1 : 0;
-    }
-    unsigned seen = 0;     // DMA waves: layers of this launch known to be published by all nine tiles
-    // DMAs of one step: weight slab of (layer l, cout group cg, chunk c), then input chunk c -- after the nine tiles
-    // have published the layer that produced it (chunks 4.. hold x1..: chunk c belongs to x_((c-4)/2+1)).
-    // Exactly kdma wave instructions.
-    auto dma_step = [&](int l, int cg, int c, int slot) {
-        const int CG = l == 4 ? 2 : 1;
-        const char* wsrc = static_cast<const char*>(a.w[l]) + ((size_t)c * CG + cg) * W_BYTES;
-#pragma unroll
-        for (int j = 0; j < W_ROUNDS; ++j) {
-            const int k = tid + THREADS * j;
-            const unsigned dst = lds_base + WRING + slot * W_BYTES + j * (THREADS * 16) + wave * 1024;
-            if (k < W_ITEMS && !(NESR_RDB_ABL & 64)) glds16_s(wsrc, (unsigned)k * 16u, __builtin_amdgcn_readfirstlane(dst));
-        }
-        const unsigned need = c < 4 ? 0u : (unsigned)((c - 4) >> 1) + 1u;
-        if (need > seen && !(NESR_RDB_ABL & 1)) {
-            const unsigned target = a.epoch + need;
-            for (unsigned it = 0;; ++it) {
-                const unsigned v = watch ? __hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
-                if (__builtin_amdgcn_ballot_w64((int)(v - target) < 0) == 0ull) break;
-                if (it > (1u << 22)) {     // ~1 s: a neighbour never arrived (workgroups not co-resident?)
-                    if (lane == 0) __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(4);
-            }
-            seen = need;
-        }
-        const char* isrc = in_img + (long long)c * a.chunk_bytes;
-#pragma unroll
-        for (int i = 0; i < IN_ROUNDS; ++i) {
-            const unsigned dst = lds_base + slot * IN_BYTES + i * (THREADS * 16) + wave * 1024;
-            if (((wavemask >> i) & 1u) && !(NESR_RDB_ABL & 32)) {          // wave-uniform: the instruction count is the same every step
-                if ((okmask >> i) & 1u) {
-                    if (NESR_RDB_ABL & 2) glds16_s(isrc, voff[i], __builtin_amdgcn_readfirstlane(dst));
-                    else glds16_s_sc1(isrc, voff[i], __builtin_amdgcn_readfirstlane(dst));
-                }
-            }
-        }
-    };
+    const int j16 = lane & 15, g4 = lane >> 4;
     // (layer, cout group, chunk) of the step after (l, cg, c); l == 5: past the end
     auto advance = [](int& l, int& cg, int& c) {
         const int nc = l == 4 ? 12 : 4 + 2 * l, ncg = l == 4 ? 2 : 1;
         if (++c == nc) { c = 0; if (++cg == ncg) { cg = 0; ++l; } }
     };
-    int fl = 0, fcg = 0, fc = 0;      // DMA waves: the next step to fetch
+
+    // The two roles run separate loops over the same 52 steps (one s_barrier per step, one more before the last
+    // epilogue): their register sets never coexist.
     if (is_dma) {
+#ifndef NESR_RDB_NOPRIO
+        __builtin_amdgcn_s_setprio(3);     // everything waits for what these four waves issue: they win the issue arbitration
+#endif
+        // ---- the plan (once per block) and the neighbours' progress words
+        const unsigned lds_base = (unsigned)(size_t)(lds_char*)(smem);
+        unsigned voff[IN_ROUNDS];
+        unsigned okmask = 0;       // per lane: rounds in which this lane has an in-image item
+        unsigned wavemask = 0;     // wave-uniform: rounds in which any lane of the wave has one (= instructions issued)
+        const int row0 = y0 > 0 ? y0 - 1 : 0;
+        const char* in_img = static_cast<const char*>(a.cur) + ((size_t)n * a.h + row0) * a.w_ * 64;
+        const unsigned* watch = nullptr;    // lanes 0..8: progress word of tile (ty + i/3 - 1, tx + i%3 - 1), if it exists
+        int kdma = 0;                       // LDS-DMA instructions this wave issues per step (vmcnt counts wave instructions)
+        if (lane < 9) {
+            const int ny = ty + lane / 3 - 1, nx = tx + lane % 3 - 1;
+            if (ny >= 0 && ny < tiles_y && nx >= 0 && nx < tiles_x) watch = a.progress + (n * tiles_y + ny) * tiles_x + nx;
+        }
+        {
+            int p = tid >> 2;
+            int py = p / PW, px = p - py * PW;
+            const int sl = tid & 3;
+#pragma unroll
+            for (int i = 0; i < IN_ROUNDS; ++i) {
+                const int k = tid + THREADS * i;
+                const int sg = sl ^ (((px >> 2) & 1) << 1);
+                const int Y = y0 - 1 + py, X = x0 - 1 + px;
+                const bool has = k < IN_ITEMS;
+                const bool ok = has && Y >= 0 && Y < a.h && X >= 0 && X < a.w_;
+                voff[i] = ((unsigned)(Y - row0) * (unsigned)a.w_ + (unsigned)X) * 64u + sg * 16;
+                okmask |= ok ? (1u << i) : 0u;
+                if (__builtin_amdgcn_ballot_w64(ok) != 0ull) { wavemask |= 1u << i; ++kdma; }
+                if (has && !ok) {
+#pragma unroll
+                    for (int sl2 = 0; sl2 < RSLOTS; ++sl2) *reinterpret_cast<f32x4*>(smem + sl2 * IN_BYTES + k * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                px += (THREADS / 4) % PW;
+                py += (THREADS / 4) / PW;
+                if (px >= PW) { px -= PW; py += 1; }
+            }
+#pragma unroll
+            for (int j = 0; j < W_ROUNDS; ++j) kdma += (wave * 64 + THREADS * j) < W_ITEMS ? 1 : 0;
+        }
+        unsigned seen = 0;     // layers of this launch known to be published by all nine tiles
+        // DMAs of one step: weight slab of (layer l, cout group cg, chunk c), then input chunk c -- after the nine tiles
+        // have published the layer that produced it (chunks 4.. hold x1..: chunk c belongs to x_((c-4)/2+1)).
+        // Exactly kdma wave instructions.
+        auto dma_step = [&](int l, int cg, int c, int slot) {
+            const int CG = l == 4 ? 2 : 1;
+            const char* wsrc = static_cast<const char*>(a.w[l]) + ((size_t)c * CG + cg) * W_BYTES;
+#pragma unroll
+            for (int j = 0; j < W_ROUNDS; ++j) {
+                const int k = tid + THREADS * j;
+                const unsigned dst = lds_base + WRING + slot * W_BYTES + j * (THREADS * 16) + wave * 1024;
+                if (k < W_ITEMS && !(NESR_RDB_ABL & 64)) glds16_s(wsrc, (unsigned)k * 16u, __builtin_amdgcn_readfirstlane(dst));
+            }
+            const unsigned need = c < 4 ? 0u : (unsigned)((c - 4) >> 1) + 1u;
+            if (need > seen && !(NESR_RDB_ABL & 1)) {
+                const unsigned target = a.epoch + need;
+                for (unsigned it = 0;; ++it) {
+                    const unsigned v = watch ? __hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+                    if (__builtin_amdgcn_ballot_w64((int)(v - target) < 0) == 0ull) break;
+                    if (it > (1u << 22)) {     // ~1 s: a neighbour never arrived (workgroups not co-resident?)
+                        if (lane == 0) __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                seen = need;
+            }
+            const char* isrc = in_img + (long long)c * a.chunk_bytes;
+#pragma unroll
+            for (int i = 0; i < IN_ROUNDS; ++i) {
+                const unsigned dst = lds_base + slot * IN_BYTES + i * (THREADS * 16) + wave * 1024;
+                if (((wavemask >> i) & 1u) && !(NESR_RDB_ABL & 32)) {          // wave-uniform: the instruction count is the same every step
+                    if ((okmask >> i) & 1u) {
+                        if (NESR_RDB_ABL & 2) glds16_s(isrc, voff[i], __builtin_amdgcn_readfirstlane(dst));
+                        else glds16_s_sc1(isrc, voff[i], __builtin_amdgcn_readfirstlane(dst));
+                    }
+                }
+            }
+        };
+        const int cbl = (g4 & 1) * 16 + (g4 >> 1) * 8;      // a lane's 8 output channels inside a 32-cout group after the permlane16 exchange
+        const int piece8 = ((g4 & 1) * 2 + (g4 >> 1)) * 8;  // its 16-byte piece of a 64-byte slot after regroup_pairs (2-byte units)
+        bool bad = false;
+        // epilogue of (layer l, cout group cg) from the staging area: conv1..4 -> LeakyReLU into cur's channels
+        // 64 + 32 l; conv5 -> x5 * s1 + x0 (and * s2 + RRDB input) into `out`'s channels 32 cg.  DMA wave d finishes
+        // the rows of MFMA waves 2d and 2d + 1.
+        // Operands of an epilogue piece (bias, conv5's residuals) are fetched one step ahead, BEFORE that step's LDS-DMAs, and
+        // first touched right after the next barrier: the compiler waits vmcnt(0) for its own loads, which at that point
+        // means "the DMA group of a step ago has landed" and not "the group issued a moment ago has".
+#if NESR_RDB_ABL & 256
+        int dbg_step = 0;
+#endif
+        f32x4 pbz0 = {0.f, 0.f, 0.f, 0.f}, pbz1 = pbz0;
+        f32x4 pr1[2][2][2] = {}, pr2[2][2][2] = {};   // [row of this wave][pixel half][chunk X | X + 1] pieces of x0 / of the RRDB input (raw 16 bytes)
+        auto ld16 = [](const void* p) -> f32x4 { return *reinterpret_cast<const f32x4*>(p); };
+        // first use of what the previous step prefetched: placed right after the barrier, where the compiler's wait for these
+        // loads finds nothing younger in flight than the DMA group issued a whole step ago
+        auto touch = [&]() {
+            asm volatile("" ::"v"(pbz0), "v"(pbz1));
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+                asm volatile("" ::"v"(pr1[0][nh][0]), "v"(pr1[0][nh][1]), "v"(pr2[0][nh][0]), "v"(pr2[0][nh][1]));
+                asm volatile("" ::"v"(pr1[1][nh][0]), "v"(pr1[1][nh][1]), "v"(pr2[1][nh][0]), "v"(pr2[1][nh][1]));
+            }
+        };
+        const long long chunk_el = a.chunk_bytes >> 1;
+        auto pix_of = [&](int row, int nh, bool& valid) -> size_t {
+            const int X = x0 + 16 * nh + j16;
+            valid = X < a.w_;
+            return ((size_t)n * a.h + (y0 + row)) * a.w_ + (valid ? X : 0);
+        };
+        auto prefetch = [&](int l, int cg, int rr, bool with_bias) {
+            if (with_bias) {
+                pbz0 = ld16(a.bias[l] + 32 * cg + cbl);
+                pbz1 = ld16(a.bias[l] + 32 * cg + cbl + 4);
+            }
+            const int row = (MW / DW) * wave + rr;
+            if (l == 4 && y0 + row < a.h) {
+                const uint16_t* cur16 = static_cast<const uint16_t*>(a.cur);
+                const uint16_t* res2 = static_cast<const uint16_t*>(a.res2);
+#pragma unroll
+                for (int nh = 0; nh < 2; ++nh) {
+                    bool valid;
+                    const size_t o = (size_t)(2 * cg) * chunk_el + pix_of(row, nh, valid) * 32 + piece8;
+                    if (rr == 0) {      // rr is a compile-time constant at every call site
+                        pr1[0][nh][0] = ld16(cur16 + o);
+                        pr1[0][nh][1] = ld16(cur16 + o + chunk_el);
+                        if (res2) { pr2[0][nh][0] = ld16(res2 + o); pr2[0][nh][1] = ld16(res2 + o + chunk_el); }
+                    } else {
+                        pr1[1][nh][0] = ld16(cur16 + o);
+                        pr1[1][nh][1] = ld16(cur16 + o + chunk_el);
+                        if (res2) { pr2[1][nh][0] = ld16(res2 + o); pr2[1][nh][1] = ld16(res2 + o + chunk_el); }
+                    }
+                }
+            }
+        };
+        auto unpack_res = [&](f32x4 rx, f32x4 rx1, f32x4& q0, f32x4& q1) {
+            uint4 cx = __builtin_bit_cast(uint4, rx), cx1 = __builtin_bit_cast(uint4, rx1);
+            regroup_pairs(cx, cx1);      // -> own hi, own lo
+            const f16x8 h = __builtin_bit_cast(f16x8, cx), lo = __builtin_bit_cast(f16x8, cx1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                q0[i] = fmaf((float)lo[i], LO_INV, (float)h[i]);
+                q1[i] = fmaf((float)lo[4 + i], LO_INV, (float)h[4 + i]);
+            }
+        };
+        // epilogue of (layer l, cout group cg), row rr of this wave, from the staging area: conv1..4 -> LeakyReLU into
+        // cur's channels 64 + 32 l; conv5 -> x5 * s1 + x0 (and * s2 + RRDB input) into `out`'s channels 32 cg.  DMA wave d
+        // finishes the rows of MFMA waves 2d and 2d + 1.  Operands: prefetch(l, cg, rr) of the step before.
+        auto epilogue = [&](int l, int cg, int rr) {
+            const uint16_t* cur16 = static_cast<const uint16_t*>(a.cur);
+            const bool has_res2 = a.res2 != nullptr;
+            uint16_t* dst16 = l == 4 ? static_cast<uint16_t*>(a.out) : const_cast<uint16_t*>(cur16);
+            const int row = (MW / DW) * wave + rr;
+            if (y0 + row >= a.h) return;          // wave-uniform
+            // the MFMA lane (j16, g) left couts 16 mt + 4 g + i of its pixel at [nh, mt][lane]: this lane wants the 8
+            // consecutive couts cbl .. cbl + 7 = two such runs, g = (cbl & 15) / 4 and the next one (the LDS does the
+            // exchange that the per-layer kernel makes with v_permlane16_swap)
+            const char* stg = smem + STAGE + row * 4096 + ((cbl >> 4) * 1024) + (j16 + 16 * ((cbl & 15) >> 2)) * 16;
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+                f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + nh * 2048);
+                f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + nh * 2048 + 256);
+#if NESR_RDB_ABL & 256
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (wave == 0) RSTAMP(1, dbg_step, 4 + 2 * nh);
+#endif
+                bool valid;
+                const size_t pix = pix_of(row, nh, valid);
+                v0 += pbz0;
+                v1 += pbz1;
+                if (l < 4) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v0[i] = fmaxf(v0[i], v0[i] * 0.2f); v1[i] = fmaxf(v1[i], v1[i] * 0.2f); }   // LeakyReLU(0.2), same values as the select form
+                } else {
+                    f32x4 q0, q1;
+                    if (rr == 0) unpack_res(pr1[0][nh][0], pr1[0][nh][1], q0, q1); else unpack_res(pr1[1][nh][0], pr1[1][nh][1], q0, q1);   // x0's couts 32 cg ..
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s1), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s1), q1[i]); }
+                    if (has_res2) {
+                        if (rr == 0) unpack_res(pr2[0][nh][0], pr2[0][nh][1], q0, q1); else unpack_res(pr2[1][nh][0], pr2[1][nh][1], q0, q1);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s2), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s2), q1[i]); }
+                    }
+                }
+                uint4 cx, cx1;
+                bool bad_here = false;
+                split_regroup(v0, v1, cx, cx1, bad_here);
+                bad |= bad_here && valid;
+#if NESR_RDB_ABL & 256
+                if (wave == 0) RSTAMP(1, dbg_step, 5 + 2 * nh);
+#endif
+                if (!valid) continue;
+                uint16_t* pd = dst16 + (size_t)(l == 4 ? 2 * cg : 4 + 2 * l) * chunk_el + pix * 32 + piece8;
+                if (l < 4 && !(NESR_RDB_ABL & 4)) {
+                    store16_wt(pd, cx);
+                    store16_wt(pd + chunk_el, cx1);
+                } else {
+                    *reinterpret_cast<uint4*>(pd) = cx;
+                    *reinterpret_cast<uint4*>(pd + chunk_el) = cx1;
+                }
+            }
+        };
+
+        int fl = 0, fcg = 0, fc = 0;      // the next step to fetch
         dma_step(0, 0, 0, 0);
         advance(fl, fcg, fc);
         dma_step(fl, fcg, fc, 1);
         advance(fl, fcg, fc);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero padding is in LDS before the first barrier
+        int fill = 2;
+        int cl = 0, ccg = 0, cc = 0;      // the current step
+        int pub_level = 0;                // > 0: that layer's stores were issued in the previous step -- publish at this barrier
+        int ep_l = 0, ep_cg = 0, ep_rr = MW / DW;   // the epilogue in progress: one of this wave's rows per step
+        for (int step = 0; step < 52; ++step) {
+            // this step's DMAs have landed (the next step's, issued one step ago, may stay in flight; after an epilogue
+            // everything drains, so that its stores have retired before the progress word goes out)
+#if NESR_RDB_ABL & 256
+            dbg_step = step;
+#endif
+            if (wave == 0) RSTAMP(1, step, 0);
+            wait_vmcnt_le((pub_level > 0 || step == 51 || (NESR_RDB_ABL & 96)) ? 0 : kdma);
+            if (wave == 0) RSTAMP(1, step, 1);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (wave == 0) RSTAMP(1, step, 2);
+            if (pub_level > 0) {
+                if (wave == 0 && lane == 0)
+                    __hip_atomic_store(a.progress + tile, a.epoch + (unsigned)pub_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pub_level = 0;
+            }
+            touch();
+            // operands of the epilogue piece of the NEXT step, ahead of this step's DMAs (see prefetch)
+            {
+                const int nc = cl == 4 ? 12 : 4 + 2 * cl;
+                if (cc == nc - 1) prefetch(cl, ccg, 0, true);                                  // row 0 of the layer that ends with this step
+                else if (cc == 0 && step > 0) prefetch(ccg == 1 ? 4 : cl - 1, 0, 1, false);     // row 1 of the layer that has just ended
+            }
+            if (fl < 5) {      // two steps ahead, into the slot read one step ago
+                dma_step(fl, fcg, fc, fill);
+                advance(fl, fcg, fc);
+                fill = fill == RSLOTS - 1 ? 0 : fill + 1;
+            }
+            // the first step of a (layer, cout group): the previous one's sums are in the staging area.  One row now, the
+            // other in the next step, so that this wave is never much later at a barrier than the MFMA waves
+            if (wave == 0) RSTAMP(1, step, 3);
+            if (cc == 0 && step > 0) { ep_l = ccg == 1 ? 4 : cl - 1; ep_cg = 0; ep_rr = 0; }
+            if (ep_rr < MW / DW) {
+                if (!(NESR_RDB_ABL & 16)) { if (ep_rr == 0) epilogue(ep_l, ep_cg, 0); else epilogue(ep_l, ep_cg, 1); }
+                if (++ep_rr == MW / DW && ep_l < 4) pub_level = ep_l + 1;
+            }
+            advance(cl, ccg, cc);
+        }
+        // the last layer's epilogue: nothing is left to overlap it with
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (!(NESR_RDB_ABL & 16)) {
+            epilogue(4, 1, 0);              // operands prefetched in step 51
+            prefetch(4, 1, 1, false);
+            epilogue(4, 1, 1);
+        }
+        if (bad && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
     }
 
-    // ---- MFMA role: operand addresses as in conv3x3_f16x2_kernel
-    const bool active = is_cmp && (y0 + RW * wave) < a.h;
-    const int j16 = lane & 15, g4 = lane >> 4, un = g4 >> 1, kh = g4 & 1;
+    // ---- MFMA role: operand addresses as in conv3x3_f16x2_kernel, one row per wave
+    const bool active = (y0 + wave) < a.h;
+    const int un = g4 >> 1, kh = g4 & 1;
     int b16[5][2], a16[5];
 #pragma unroll
     for (int st_ = 0; st_ < 5; ++st_) {
@@ -717,55 +930,41 @@ __global__ __launch_bounds__(64 * (WAVES + 4), 2) void rdb_f16x2_kernel(RdbArgs 
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh) {
             const int col = 16 * nh + j16 + dx;
-            b16[st_][nh] = ((RW * wave + dy) * PW + col) * 64 + ((kh ^ (((col >> 2) & 1) << 1)) << 4);
+            b16[st_][nh] = ((wave + dy) * PW + col) * 64 + ((kh ^ (((col >> 2) & 1) << 1)) << 4);
         }
         a16[st_] = ((((dy * 3 + dx) * 2) * 2 + kh) * 32 + j16) * 16;
     }
-    const int cbl = (g4 & 1) * 16 + (g4 >> 1) * 8;    // this lane's 8 output channels inside a 32-cout group after the permlane16 exchange
-    const int piece8 = ((g4 & 1) * 2 + (g4 >> 1)) * 8;  // its 16-byte piece of a 64-byte slot after regroup_pairs (2-byte units)
-    bool bad = false;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero padding is in LDS before the first barrier
-
-    int slot = 0, fill = 2;     // ring slot of the current step / of the step being fetched
-    int pub_level = 0, pub_wait = 0;
+    int slot = 0;       // ring slot of the current step
+#if NESR_RDB_ABL & 256
+    int mstep = 0;
+#endif
     for (int l = 0; l < 5; ++l) {
         const int nc = l == 4 ? 12 : 4 + 2 * l;
         const int ncg = l == 4 ? 2 : 1;
         for (int cg = 0; cg < ncg; ++cg) {
-            f32x4 acc16[RW][2][2][2];
+            f32x4 acc16[2][2][2];       // [pixel half][cout half][main | cross]
 #pragma unroll
-            for (int r = 0; r < RW; ++r)
+            for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-                for (int nh = 0; nh < 2; ++nh)
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) acc16[r][nh][mt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 bz0 = f32x4{0.f, 0.f, 0.f, 0.f}, bz1 = bz0;
-            if (is_cmp) {
-                bz0 = *reinterpret_cast<const f32x4*>(a.bias[l] + 32 * cg + cbl);
-                bz1 = *reinterpret_cast<const f32x4*>(a.bias[l] + 32 * cg + cbl + 4);
-            }
+                    for (int q = 0; q < 2; ++q) acc16[nh][mt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int c = 0; c < nc; ++c) {
-                // DMA waves: this step's DMAs have landed (the next step's, issued one step ago, may still be in flight;
-                // none are after the last fetch).  MFMA waves: a layer's stores must have retired before its progress
-                // word goes out -- and they wait only then (they hold no other VM ops)
-                const bool publish_now = pub_wait > 0 && --pub_wait == 0;
-                if (is_dma) wait_vmcnt_le((NESR_RDB_ABL & 96) ? 0 : (fl < 5 || (l == 4 && cg == 1 && c < nc - 1) ? kdma : 0));
-                else if (publish_now) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // the staging writes of the previous layer (if any) have completed before the barrier that hands them over
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if NESR_RDB_ABL & 256
+                if (wave == 1) RSTAMP(0, mstep, 0);
+#endif
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
-                if (publish_now && wave_all == 0 && lane == 0)
-                    __hip_atomic_store(a.progress + tile, a.epoch + (unsigned)pub_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (is_dma && fl < 5) {      // two steps ahead, into the slot read one step ago
-                    dma_step(fl, fcg, fc, fill);
-                    advance(fl, fcg, fc);
-                }
+#if NESR_RDB_ABL & 256
+                if (wave == 1) RSTAMP(0, mstep, 1);
+#endif
                 if (active && !(NESR_RDB_ABL & 8)) {
                     const char* st = smem + slot * IN_BYTES;
                     const char* swb = smem + WRING + slot * W_BYTES;
-                    f32x4 Af[2][2][2];
-                    f32x4 Bf[2][RW][2][2];
+                    f32x4 Af[2][2][2];     // [buffer][cout half][variant]
+                    f32x4 Bf[2][2][2];     // [buffer][pixel half][variant]
                     auto load_step = [&](int s_, int buf) {
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt) {
@@ -780,14 +979,12 @@ __global__ __launch_bounds__(64 * (WAVES + 4), 2) void rdb_f16x2_kernel(RdbArgs 
                             }
                         }
 #pragma unroll
-                        for (int r = 0; r < RW; ++r)
-#pragma unroll
-                            for (int nh = 0; nh < 2; ++nh) {
-                                const int o0 = b16[s_][nh];
-                                const int o1 = s_ == 4 ? (b16[4][nh] ^ ((un ^ 1) << 5)) : (b16[s_][nh] ^ 32);
-                                Bf[buf][r][nh][0] = *reinterpret_cast<const f32x4*>(st + o0 + r * (PW * 64));
-                                Bf[buf][r][nh][1] = *reinterpret_cast<const f32x4*>(st + o1 + r * (PW * 64));
-                            }
+                        for (int nh = 0; nh < 2; ++nh) {
+                            const int o0 = b16[s_][nh];
+                            const int o1 = s_ == 4 ? (b16[4][nh] ^ ((un ^ 1) << 5)) : (b16[s_][nh] ^ 32);
+                            Bf[buf][nh][0] = *reinterpret_cast<const f32x4*>(st + o0);
+                            Bf[buf][nh][1] = *reinterpret_cast<const f32x4*>(st + o1);
+                        }
                     };
                     load_step(0, 0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -799,110 +996,59 @@ __global__ __launch_bounds__(64 * (WAVES + 4), 2) void rdb_f16x2_kernel(RdbArgs 
 #pragma unroll
                             for (int mt = 0; mt < 2; ++mt) { asm volatile("" ::"v"(Af[buf][mt][0]), "v"(Af[buf][mt][1])); }
 #pragma unroll
-                            for (int r = 0; r < RW; ++r)
-#pragma unroll
-                                for (int nh = 0; nh < 2; ++nh) { asm volatile("" ::"v"(Bf[buf][r][nh][0]), "v"(Bf[buf][r][nh][1])); }
+                            for (int nh = 0; nh < 2; ++nh) { asm volatile("" ::"v"(Bf[buf][nh][0]), "v"(Bf[buf][nh][1])); }
                             continue;
                         }
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt) {
                             const f16x8 a0 = __builtin_bit_cast(f16x8, Af[buf][mt][0]), a1 = __builtin_bit_cast(f16x8, Af[buf][mt][1]);
 #pragma unroll
-                            for (int r = 0; r < RW; ++r)
-#pragma unroll
-                                for (int nh = 0; nh < 2; ++nh) {
-                                    const f16x8 x0_ = __builtin_bit_cast(f16x8, Bf[buf][r][nh][0]), x1_ = __builtin_bit_cast(f16x8, Bf[buf][r][nh][1]);
-                                    if (s_ < 4) {
-                                        acc16[r][nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x1_, acc16[r][nh][mt][1], 0, 0, 0);
-                                        acc16[r][nh][mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x0_, acc16[r][nh][mt][0], 0, 0, 0);
-                                        acc16[r][nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x0_, acc16[r][nh][mt][1], 0, 0, 0);
-                                    } else {
-                                        acc16[r][nh][mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x0_, acc16[r][nh][mt][0], 0, 0, 0);
-                                        acc16[r][nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1_, acc16[r][nh][mt][1], 0, 0, 0);
-                                    }
+                            for (int nh = 0; nh < 2; ++nh) {
+                                const f16x8 x0_ = __builtin_bit_cast(f16x8, Bf[buf][nh][0]), x1_ = __builtin_bit_cast(f16x8, Bf[buf][nh][1]);
+                                if (s_ < 4) {
+                                    acc16[nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x1_, acc16[nh][mt][1], 0, 0, 0);
+                                    acc16[nh][mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x0_, acc16[nh][mt][0], 0, 0, 0);
+                                    acc16[nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x0_, acc16[nh][mt][1], 0, 0, 0);
+                                } else {
+                                    acc16[nh][mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x0_, acc16[nh][mt][0], 0, 0, 0);
+                                    acc16[nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1_, acc16[nh][mt][1], 0, 0, 0);
                                 }
+                            }
                         }
+                        // the next step's 8 fragment reads ride between this step's MFMAs
                         if (s_ + 1 < 5) {
 #pragma unroll
-                            for (int i = 0; i < 4 + 4 * RW; ++i) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            for (int i = 0; i < 8; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 slot = slot == RSLOTS - 1 ? 0 : slot + 1;
-                fill = fill == RSLOTS - 1 ? 0 : fill + 1;
+#if NESR_RDB_ABL & 256
+                if (wave == 1) RSTAMP(0, mstep, 2);
+                ++mstep;
+#endif
             }
-            // ---- epilogue of (layer l, cout group cg): conv1..4 -> LeakyReLU into cur's channels 64 + 32 l;
-            // conv5 -> x5 * s1 + x0 (and * s2 + RRDB input) into `out`'s channels 32 cg
-            if (NESR_RDB_ABL & 16) {     // no epilogue; the accumulators stay live (no dead-code elimination of the K loop)
+            // the layer's sums -> staging area (main + cross / 2^11): [row][pixel half, cout half][lane]
+            if (active) {
+                char* stg = smem + STAGE + wave * 4096 + lane * 16;
 #pragma unroll
-                for (int r = 0; r < RW; ++r)
+                for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-                    for (int nh = 0; nh < 2; ++nh)
+                    for (int mt = 0; mt < 2; ++mt) {
+                        f32x4 e;
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) asm volatile("" ::"v"(acc16[r][nh][mt][0]), "v"(acc16[r][nh][mt][1]));
-            }
-            if (active && !(NESR_RDB_ABL & 16)) {
-                const uint16_t* cur16 = static_cast<const uint16_t*>(a.cur);
-                const uint16_t* res2 = static_cast<const uint16_t*>(a.res2);
-                uint16_t* dst16 = l == 4 ? static_cast<uint16_t*>(a.out) : const_cast<uint16_t*>(cur16);
-                const long long chunk_el = a.chunk_bytes >> 1;
-#pragma unroll
-                for (int r = 0; r < RW; ++r)
-#pragma unroll
-                    for (int nh = 0; nh < 2; ++nh) {
-                        const int Y = y0 + RW * wave + r, X = x0 + 16 * nh + j16;
-                        const bool valid = X < a.w_ && Y < a.h;
-                        const size_t pix = ((size_t)n * a.h + (Y < a.h ? Y : 0)) * a.w_ + (X < a.w_ ? X : 0);
-                        f32x4 v0, v1;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float e = fmaf(acc16[r][nh][0][1][i], LO_INV, acc16[r][nh][0][0][i]);
-                            const float o = fmaf(acc16[r][nh][1][1][i], LO_INV, acc16[r][nh][1][0][i]);
-                            const auto sw_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(e), __float_as_uint(o), false, false);
-                            v0[i] = __uint_as_float(sw_[0]);
-                            v1[i] = __uint_as_float(sw_[1]);
-                        }
-                        v0 += bz0;
-                        v1 += bz1;
-                        // slot of this pixel in chunk `ch` of a [chunks][pixels][64 B] buffer, at this lane's piece
-                        auto slot = [&](int ch) -> size_t { return (size_t)ch * chunk_el + pix * 32 + piece8; };
-                        if (l < 4) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) { v0[i] = v0[i] > 0.f ? v0[i] : v0[i] * 0.2f; v1[i] = v1[i] > 0.f ? v1[i] : v1[i] * 0.2f; }
-                        } else {
-                            f32x4 q0, q1;
-                            load_regrouped(cur16 + slot(2 * cg), chunk_el, q0, q1);      // x0's couts 32 cg ..
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s1), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s1), q1[i]); }
-                            if (res2) {
-                                load_regrouped(res2 + slot(2 * cg), chunk_el, q0, q1);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s2), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s2), q1[i]); }
-                            }
-                        }
-                        uint4 cx, cx1;
-                        bool bad_here = false;
-                        split_regroup(v0, v1, cx, cx1, bad_here);
-                        bad |= bad_here && valid;
-                        if (!valid) continue;
-                        uint16_t* pd = dst16 + slot(l == 4 ? 2 * cg : 4 + 2 * l);
-                        if (l < 4 && !(NESR_RDB_ABL & 4)) {
-                            store16_wt(pd, cx);
-                            store16_wt(pd + chunk_el, cx1);
-                        } else {
-                            *reinterpret_cast<uint4*>(pd) = cx;
-                            *reinterpret_cast<uint4*>(pd + chunk_el) = cx1;
-                        }
+                        for (int i = 0; i < 4; ++i) e[i] = fmaf(acc16[nh][mt][1][i], LO_INV, acc16[nh][mt][0][i]);
+                        *reinterpret_cast<f32x4*>(stg + (nh * 2 + mt) * 1024) = e;
                     }
             }
-            if (l < 4) { pub_level = l + 1; pub_wait = NESR_RDB_PUB_DELAY; }
         }
     }
-    if (bad && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 }
 
 template <int DMAW>
@@ -929,6 +1075,11 @@ inline float h2f(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
 
 }  // namespace
 
+#if NESR_RDB_ABL & 256
+extern "C" int nesr_debug_rdb_stamps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rdb_stamps), sizeof(unsigned long long) * 2 * 64 * 8);
+}
+#endif
 #if NESR_ABL & 64
 extern "C" int nesr_debug_stamps(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (n < 256 ? n : 256));
@@ -962,7 +1113,7 @@ int rdb_f16x2_tiles(int n, int h, int w) { return ((w + TW - 1) / TW) * ((h + 7)
 
 hipError_t launch_rdb_f16x2(const RdbLaunch& r, hipStream_t s) {
     typedef Geo<4> G;
-    constexpr size_t shm = (size_t)RSLOTS * (G::IN_BYTES + (size_t)W_BYTES);
+    constexpr size_t shm = (size_t)RSLOTS * (G::IN_BYTES + (size_t)W_BYTES) + STAGE_BYTES;
     static unsigned long long attr_done = 0;
     {
         const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&rdb_f16x2_kernel), shm, attr_done);
@@ -976,7 +1127,7 @@ hipError_t launch_rdb_f16x2(const RdbLaunch& r, hipStream_t s) {
     a.progress = r.progress; a.epoch = r.epoch; a.abort_flag = r.abort_flag; a.status = r.status;
     const int total = rdb_f16x2_tiles(r.n, r.h, r.w_);
     if (total <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rdb_f16x2_kernel, dim3((unsigned)total), dim3(G::LAUNCH_THREADS), shm, s, a);
+    hipLaunchKernelGGL(rdb_f16x2_kernel, dim3((unsigned)total), dim3(64 * (MW + DW)), shm, s, a);
     return hipGetLastError();
 }
 

@@ -19,5 +19,5 @@ for arg in sys.argv[1:]:
             agg[k][1] += float(r["Counter_Value"])
         print("#", f)
         for (name, ctr), (n, tot) in sorted(agg.items()):
-            if "conv3x3" in name or "pack" in name:
+            if "conv3x3" in name or "pack" in name or "rdb" in name:
                 print(f"{name:50s} {ctr:28s} dispatches {n:6d}  sum {tot:.6g}  per-dispatch {tot / n:.6g}")
