@@ -621,6 +621,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
     constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
     constexpr int WRING = RSLOTS * IN_BYTES;             // LDS: [input ring][weight ring][staging]
     constexpr int STAGE = RSLOTS * (IN_BYTES + W_BYTES);
+    constexpr int BIAS = STAGE + STAGE_BYTES;            // 6 x 32 f32: conv1..conv4, conv5 couts 0-31, conv5 couts 32-63
     static_assert(TH == MW, "one tile row per MFMA wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -740,56 +741,23 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
         // epilogue of (layer l, cout group cg) from the staging area: conv1..4 -> LeakyReLU into cur's channels
         // 64 + 32 l; conv5 -> x5 * s1 + x0 (and * s2 + RRDB input) into `out`'s channels 32 cg.  DMA wave d finishes
         // the rows of MFMA waves 2d and 2d + 1.
-        // Operands of an epilogue piece (bias, conv5's residuals) are fetched one step ahead, BEFORE that step's LDS-DMAs, and
-        // first touched right after the next barrier: the compiler waits vmcnt(0) for its own loads, which at that point
-        // means "the DMA group of a step ago has landed" and not "the group issued a moment ago has".
+        // The six bias vectors of the block sit in LDS (768 B, filled once below): a global load inside the loop would
+        // make the compiler wait vmcnt(0) around it -- i.e. for the LDS-DMAs issued a moment ago -- at every join of the
+        // loop's control flow (measured: the DMA skeleton went from 0.76 to 1.28 us per step).  conv5's residual loads
+        // stay where they are used, inside the l == 4 branch of the epilogue: two pieces per launch pay their latency.
 #if NESR_RDB_ABL & 256
         int dbg_step = 0;
 #endif
-        f32x4 pbz0 = {0.f, 0.f, 0.f, 0.f}, pbz1 = pbz0;
-        f32x4 pr1[2][2][2] = {}, pr2[2][2][2] = {};   // [row of this wave][pixel half][chunk X | X + 1] pieces of x0 / of the RRDB input (raw 16 bytes)
-        auto ld16 = [](const void* p) -> f32x4 { return *reinterpret_cast<const f32x4*>(p); };
-        // first use of what the previous step prefetched: placed right after the barrier, where the compiler's wait for these
-        // loads finds nothing younger in flight than the DMA group issued a whole step ago
-        auto touch = [&]() {
-            asm volatile("" ::"v"(pbz0), "v"(pbz1));
-#pragma unroll
-            for (int nh = 0; nh < 2; ++nh) {
-                asm volatile("" ::"v"(pr1[0][nh][0]), "v"(pr1[0][nh][1]), "v"(pr2[0][nh][0]), "v"(pr2[0][nh][1]));
-                asm volatile("" ::"v"(pr1[1][nh][0]), "v"(pr1[1][nh][1]), "v"(pr2[1][nh][0]), "v"(pr2[1][nh][1]));
-            }
-        };
         const long long chunk_el = a.chunk_bytes >> 1;
         auto pix_of = [&](int row, int nh, bool& valid) -> size_t {
             const int X = x0 + 16 * nh + j16;
             valid = X < a.w_;
             return ((size_t)n * a.h + (y0 + row)) * a.w_ + (valid ? X : 0);
         };
-        auto prefetch = [&](int l, int cg, int rr, bool with_bias) {
-            if (with_bias) {
-                pbz0 = ld16(a.bias[l] + 32 * cg + cbl);
-                pbz1 = ld16(a.bias[l] + 32 * cg + cbl + 4);
-            }
-            const int row = (MW / DW) * wave + rr;
-            if (l == 4 && y0 + row < a.h) {
-                const uint16_t* cur16 = static_cast<const uint16_t*>(a.cur);
-                const uint16_t* res2 = static_cast<const uint16_t*>(a.res2);
-#pragma unroll
-                for (int nh = 0; nh < 2; ++nh) {
-                    bool valid;
-                    const size_t o = (size_t)(2 * cg) * chunk_el + pix_of(row, nh, valid) * 32 + piece8;
-                    if (rr == 0) {      // rr is a compile-time constant at every call site
-                        pr1[0][nh][0] = ld16(cur16 + o);
-                        pr1[0][nh][1] = ld16(cur16 + o + chunk_el);
-                        if (res2) { pr2[0][nh][0] = ld16(res2 + o); pr2[0][nh][1] = ld16(res2 + o + chunk_el); }
-                    } else {
-                        pr1[1][nh][0] = ld16(cur16 + o);
-                        pr1[1][nh][1] = ld16(cur16 + o + chunk_el);
-                        if (res2) { pr2[1][nh][0] = ld16(res2 + o); pr2[1][nh][1] = ld16(res2 + o + chunk_el); }
-                    }
-                }
-            }
-        };
+        if (wave == 0 && lane < 48) {
+            const int l = lane >> 3 > 4 ? 4 : lane >> 3, cgq = lane >> 3 > 4 ? 8 + (lane & 7) : (lane & 7);   // lanes 32..47: conv5's 64 biases
+            *reinterpret_cast<f32x4*>(smem + BIAS + lane * 16) = *reinterpret_cast<const f32x4*>(a.bias[l] + 4 * cgq);
+        }
         auto unpack_res = [&](f32x4 rx, f32x4 rx1, f32x4& q0, f32x4& q1) {
             uint4 cx = __builtin_bit_cast(uint4, rx), cx1 = __builtin_bit_cast(uint4, rx1);
             regroup_pairs(cx, cx1);      // -> own hi, own lo
@@ -805,10 +773,12 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
         // finishes the rows of MFMA waves 2d and 2d + 1.  Operands: prefetch(l, cg, rr) of the step before.
         auto epilogue = [&](int l, int cg, int rr) {
             const uint16_t* cur16 = static_cast<const uint16_t*>(a.cur);
-            const bool has_res2 = a.res2 != nullptr;
+            const uint16_t* res2 = static_cast<const uint16_t*>(a.res2);
             uint16_t* dst16 = l == 4 ? static_cast<uint16_t*>(a.out) : const_cast<uint16_t*>(cur16);
             const int row = (MW / DW) * wave + rr;
             if (y0 + row >= a.h) return;          // wave-uniform
+            const char* bsrc = smem + BIAS + (l * 32 + 32 * cg + cbl) * 4;      // conv5's second group follows its first
+            const f32x4 pbz0 = *reinterpret_cast<const f32x4*>(bsrc), pbz1 = *reinterpret_cast<const f32x4*>(bsrc + 16);
             // the MFMA lane (j16, g) left couts 16 mt + 4 g + i of its pixel at [nh, mt][lane]: this lane wants the 8
             // consecutive couts cbl .. cbl + 7 = two such runs, g = (cbl & 15) / 4 and the next one (the LDS does the
             // exchange that the per-layer kernel makes with v_permlane16_swap)
@@ -829,12 +799,16 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { v0[i] = fmaxf(v0[i], v0[i] * 0.2f); v1[i] = fmaxf(v1[i], v1[i] * 0.2f); }   // LeakyReLU(0.2), same values as the select form
                 } else {
+                    const size_t o = (size_t)(2 * cg) * chunk_el + pix * 32 + piece8;      // x0's couts 32 cg ..
+                    const f32x4 r10 = *reinterpret_cast<const f32x4*>(cur16 + o), r11 = *reinterpret_cast<const f32x4*>(cur16 + o + chunk_el);
+                    f32x4 r20 = r10, r21 = r11;
+                    if (res2) { r20 = *reinterpret_cast<const f32x4*>(res2 + o); r21 = *reinterpret_cast<const f32x4*>(res2 + o + chunk_el); }
                     f32x4 q0, q1;
-                    if (rr == 0) unpack_res(pr1[0][nh][0], pr1[0][nh][1], q0, q1); else unpack_res(pr1[1][nh][0], pr1[1][nh][1], q0, q1);   // x0's couts 32 cg ..
+                    unpack_res(r10, r11, q0, q1);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s1), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s1), q1[i]); }
-                    if (has_res2) {
-                        if (rr == 0) unpack_res(pr2[0][nh][0], pr2[0][nh][1], q0, q1); else unpack_res(pr2[1][nh][0], pr2[1][nh][1], q0, q1);
+                    if (res2) {
+                        unpack_res(r20, r21, q0, q1);
 #pragma unroll
                         for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s2), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s2), q1[i]); }
                     }
@@ -877,20 +851,13 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
             if (wave == 0) RSTAMP(1, step, 0);
             wait_vmcnt_le((pub_level > 0 || step == 51 || (NESR_RDB_ABL & 96)) ? 0 : kdma);
             if (wave == 0) RSTAMP(1, step, 1);
-            __builtin_amdgcn_s_barrier();
+            if (!(NESR_RDB_ABL & 512)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (wave == 0) RSTAMP(1, step, 2);
             if (pub_level > 0) {
                 if (wave == 0 && lane == 0)
                     __hip_atomic_store(a.progress + tile, a.epoch + (unsigned)pub_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 pub_level = 0;
-            }
-            touch();
-            // operands of the epilogue piece of the NEXT step, ahead of this step's DMAs (see prefetch)
-            {
-                const int nc = cl == 4 ? 12 : 4 + 2 * cl;
-                if (cc == nc - 1) prefetch(cl, ccg, 0, true);                                  // row 0 of the layer that ends with this step
-                else if (cc == 0 && step > 0) prefetch(ccg == 1 ? 4 : cl - 1, 0, 1, false);     // row 1 of the layer that has just ended
             }
             if (fl < 5) {      // two steps ahead, into the slot read one step ago
                 dma_step(fl, fcg, fc, fill);
@@ -911,8 +878,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (!(NESR_RDB_ABL & 16)) {
-            epilogue(4, 1, 0);              // operands prefetched in step 51
-            prefetch(4, 1, 1, false);
+            epilogue(4, 1, 0);
             epilogue(4, 1, 1);
         }
         if (bad && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -955,7 +921,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
 #if NESR_RDB_ABL & 256
                 if (wave == 1) RSTAMP(0, mstep, 0);
 #endif
-                __builtin_amdgcn_s_barrier();
+                if (!(NESR_RDB_ABL & 512)) __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
 #if NESR_RDB_ABL & 256
                 if (wave == 1) RSTAMP(0, mstep, 1);
@@ -1113,7 +1079,7 @@ int rdb_f16x2_tiles(int n, int h, int w) { return ((w + TW - 1) / TW) * ((h + 7)
 
 hipError_t launch_rdb_f16x2(const RdbLaunch& r, hipStream_t s) {
     typedef Geo<4> G;
-    constexpr size_t shm = (size_t)RSLOTS * (G::IN_BYTES + (size_t)W_BYTES) + STAGE_BYTES;
+    constexpr size_t shm = (size_t)RSLOTS * (G::IN_BYTES + (size_t)W_BYTES) + STAGE_BYTES + 768;
     static unsigned long long attr_done = 0;
     {
         const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&rdb_f16x2_kernel), shm, attr_done);
