@@ -397,7 +397,9 @@ def main():
                               "frac": round(achieved / peak, 4), "traffic": pmc_traffic(tkey),
                               "algorithm": algo["algorithm"] if algo else "direct implicit GEMM, v_mfma_f32_32x32x16_bf16",
                               "executed_frac": round(achieved * per_alg / peak, 4),
-                              "kernel": "conv3x3_f16x2_kernel / conv3x3_wino_f32_kernel / conv3x3_mfma_kernel / conv3x3_bf16_xl_kernel (the 345 dense-block convs per frame)",
+                              "kernel": ("rdb_f16x2_kernel (conv1..conv5 of a dense block in one launch: 69 launches = the 345 dense-block convs of a frame)"
+                                         if (algo is F32_ALGOS["split"] and k_launches and k_flops / k_launches > 2e10) else
+                                         "conv3x3_f16x2_kernel / conv3x3_wino_f32_kernel / conv3x3_mfma_kernel / conv3x3_bf16_xl_kernel (the 345 dense-block convs per frame)"),
                               "avg_launch_us": round(1e3 * k_ms / max(k_launches, 1), 2), "launches": int(k_launches)}
         if inflight > 1:
             result["roofline"]["measured_on"] = (f"a second timed region of {args.steps} single-frame forwards on one stream "

@@ -25,6 +25,33 @@ from torch.nn import functional as F
 from .rrdbnet import RRDBNet
 
 
+# Integrity pins of the published checkpoints: the only ones the reference holds (nesr/utils/downloader.py:25-26, 33-34).
+KNOWN_CHECKPOINTS = {
+    "5db904e3e9f0dbf5c64b7ae665527e62": "RealESRGAN_x2plus.pth (v0.2.5.0 release, 67,010,191 bytes)",
+    "94df4e7c584b55e2e9a5d2b8f161860e": "RealESRGAN_x4plus.pth (v0.1.0 release)",
+}
+
+
+def checkpoint_provenance(path):
+    """md5 of a checkpoint file against the reference's table -> ("verified"|"unverified", description).
+    A file NAMED like a published checkpoint whose digest differs is reported with a warning (it may be a fine-tune;
+    it is not the file the reference downloads)."""
+    import hashlib
+    import os
+    h = hashlib.md5()
+    with open(path, "rb") as f:
+        for block in iter(lambda: f.read(1 << 20), b""):
+            h.update(block)
+    digest, size = h.hexdigest(), os.path.getsize(path)
+    if digest in KNOWN_CHECKPOINTS:
+        return "verified", f"{KNOWN_CHECKPOINTS[digest]}: md5 {digest} matches nesr/utils/downloader.py"
+    base = os.path.basename(str(path))
+    if base in ("RealESRGAN_x2plus.pth", "RealESRGAN_x4plus.pth"):
+        warnings.warn(f"{path}: named like a published Real-ESRGAN checkpoint but md5 {digest} ({size} bytes) is not the "
+                      "digest recorded in the reference (nesr/utils/downloader.py:25-26,33-34)")
+    return "unverified", f"{base}: md5 {digest}, {size} bytes (not a digest the reference records)"
+
+
 def _bgr2gray(img):
     # cv2.COLOR_BGR2GRAY on float32
     return (img[..., 0] * np.float32(0.114) + img[..., 1] * np.float32(0.587) + img[..., 2] * np.float32(0.299)).astype(np.float32)
@@ -77,9 +104,13 @@ class RealESRGANer:
             self.device = torch.device("cuda" if torch.cuda.is_available() else "cpu") if device is None else device
         self.device = torch.device(self.device)
 
+        # where the weights came from: "verified" only for a file whose md5 is one the reference records
+        self.weights_provenance = ("unverified", "in-memory state_dict (tests and benches use seeded synthetic weights: "
+                                                 "no checkpoint ships with the reference)")
         if isinstance(model_path, list):
             assert len(model_path) == len(dni_weight), "model_path and dni_weight should have the save length."
             loadnet = self.dni(model_path[0], model_path[1], dni_weight)
+            self.weights_provenance = ("unverified", "deep network interpolation of two checkpoints")
         elif isinstance(model_path, dict):
             loadnet = model_path
         else:
@@ -87,6 +118,7 @@ class RealESRGANer:
                 raise RuntimeError(f"{model_path}: downloading checkpoints is not supported (offline build); "
                                    "pass a local path to RealESRGAN_x2plus.pth / RealESRGAN_x4plus.pth")
             loadnet = torch.load(model_path, map_location=torch.device("cpu"), weights_only=True)
+            self.weights_provenance = checkpoint_provenance(model_path)
 
         keyname = "params_ema" if "params_ema" in loadnet else "params"
         state = loadnet[keyname]

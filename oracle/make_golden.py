@@ -86,6 +86,26 @@ def load_test_crop():
     return np.load(path)
 
 
+def test_jpeg_full_case():
+    """The reference's only asset, images/test.jpeg (512x512), through the oracle wrapper with
+    standalone/direct_esrgan.py's settings (:104, :118-127: x2plus shape, tile=512, tile_pad=10, pre_pad=0, half=False),
+    seeded synthetic 23-block weights.  Kept: the decoded input, every second pixel of the 1024x1024 result and a
+    full-resolution 256x256 window of it."""
+    path = os.path.join(GOLDEN, "test_jpeg_full.npz")
+    ref_img = "/root/reference/images/test.jpeg"
+    if not os.path.exists(ref_img):
+        return np.load(path)
+    from PIL import Image
+    bgr = np.ascontiguousarray(np.asarray(Image.open(ref_img).convert("RGB"))[:, :, ::-1])
+    sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=2, num_block=23)
+    up = RealESRGANerRef(scale=2, model_path={"params_ema": sd}, model=RRDBNetRef(3, 3, scale=2), tile=512, tile_pad=10, pre_pad=0)
+    out, mode = up.enhance(bgr)
+    assert out.shape == (1024, 1024, 3) and mode == "RGB"
+    np.savez_compressed(path, input_bgr=bgr, out_strided=np.ascontiguousarray(out[::2, ::2]),
+                        out_window=np.ascontiguousarray(out[384:640, 384:640]))
+    return np.load(path)
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.manual_seed(0)
@@ -149,6 +169,8 @@ def main():
     q, _ = up.enhance(np.ascontiguousarray(crop[:24, :40]))
     out["x4_tile16_q"] = q
     np.savez_compressed(os.path.join(GOLDEN, "wrapper.npz"), **out)
+
+    test_jpeg_full_case()
 
     for f in sorted(os.listdir(GOLDEN)):
         print(f"{f:40s} {os.path.getsize(os.path.join(GOLDEN, f)) / 1024:8.1f} KiB")

@@ -211,3 +211,19 @@ def test_enhance_many_equals_enhance(cuda_device, inflight):
         assert gm == wm and np.array_equal(g, w)
     odd = [synthetic_frame(63, 95, seed=9)]                 # needs mod-padding: falls back to enhance()
     assert np.array_equal(up.enhance_many(odd)[0][0], up.enhance(odd[0])[0])
+
+
+def test_full_test_jpeg_direct_esrgan_settings(cuda_device, golden_dir):
+    """The reference's only asset, the whole 512x512 images/test.jpeg, through the drop-in exactly as
+    standalone/direct_esrgan.py:104,118-127,148 drives it (tile=512, tile_pad=10, pre_pad=0, half=False), against the
+    committed oracle output (every second pixel + a full-resolution window).  8-bit: at most 1 LSB, on rounding ties."""
+    g = np.load(os.path.join(golden_dir, "test_jpeg_full.npz"))
+    sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=2, num_block=23)
+    up = RealESRGANer(scale=2, model_path={"params_ema": sd}, model=RRDBNet(3, 3, scale=2), tile=512, tile_pad=10, pre_pad=0,
+                      half=False, device=cuda_device)
+    assert up.weights_provenance[0] == "unverified"        # synthetic weights: said so, not implied
+    out, mode = up.enhance(g["input_bgr"])
+    assert mode == "RGB" and out.shape == (1024, 1024, 3) and up.model.calls == 1
+    for got, want in ((out[::2, ::2], g["out_strided"]), (out[384:640, 384:640], g["out_window"])):
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3, (d.max(), (d > 0).mean())

@@ -150,3 +150,21 @@ def test_https_model_path_is_refused_offline():
     with pytest.raises(RuntimeError, match="not supported"):
         RealESRGANer(scale=2, model_path="https://github.com/xinntao/Real-ESRGAN/releases/download/v0.2.5.0/x.pth",
                      model=RRDBNet(3, 3, scale=2, num_block=1), device="cpu")
+
+
+def test_checkpoint_provenance_md5(tmp_path, monkeypatch):
+    """nesr/utils/downloader.py:25-26 pins RealESRGAN_x2plus.pth by md5: a file with that digest is 'verified', anything else
+    is 'unverified', and a file merely NAMED like the published checkpoint warns."""
+    import warnings
+    from neural_enhanced_super_resolution_amd import realesrganer as R
+    p = tmp_path / "RealESRGAN_x2plus.pth"
+    p.write_bytes(b"not the real checkpoint")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        kind, text = R.checkpoint_provenance(str(p))
+    assert kind == "unverified" and any("md5" in str(x.message) for x in w)
+    import hashlib
+    digest = hashlib.md5(b"not the real checkpoint").hexdigest()
+    monkeypatch.setitem(R.KNOWN_CHECKPOINTS, digest, "stand-in for the published file")
+    assert R.checkpoint_provenance(str(p))[0] == "verified"
+    assert "5db904e3e9f0dbf5c64b7ae665527e62" in R.KNOWN_CHECKPOINTS and "94df4e7c584b55e2e9a5d2b8f161860e" in R.KNOWN_CHECKPOINTS

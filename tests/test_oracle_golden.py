@@ -106,3 +106,18 @@ def test_strict_load_rejects_wrong_arch():
     sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=2, num_block=1)
     with pytest.raises(RuntimeError):
         RRDBNetRef(3, 3, scale=4, num_block=1).load_state_dict(sd)   # 3-ch conv_first vs 12-ch weights
+
+
+def test_oracle_reproduces_the_full_test_jpeg_fixture(golden_dir):
+    """images/test.jpeg (the reference's only asset, 512x512) at standalone/direct_esrgan.py's settings: the committed
+    fixture is the oracle's output on the decoded pixels, and the oracle still produces it bit for bit."""
+    from oracle.realesrganer_ref import RealESRGANerRef
+    from oracle.rrdbnet_ref import RRDBNetRef
+    g = np.load(os.path.join(golden_dir, "test_jpeg_full.npz"))
+    bgr = g["input_bgr"]
+    assert bgr.shape == (512, 512, 3) and bgr.dtype == np.uint8 and abs(float(bgr.mean()) - 98.3) < 1.0   # SURVEY.md section 2 row 22
+    sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=2, num_block=23)
+    up = RealESRGANerRef(scale=2, model_path={"params_ema": sd}, model=RRDBNetRef(3, 3, scale=2), tile=512, tile_pad=10, pre_pad=0)
+    out, mode = up.enhance(bgr)
+    assert mode == "RGB" and out.shape == (1024, 1024, 3)
+    assert np.array_equal(out[::2, ::2], g["out_strided"]) and np.array_equal(out[384:640, 384:640], g["out_window"])
