@@ -32,6 +32,9 @@ SIGNATURES = {
     "nesr_band_begin": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
     "nesr_band_rdb": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_void_p]),
     "nesr_band_tail": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "nesr_band_rdb_phase": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p]),
+    "nesr_band_pack_edges": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
+    "nesr_band_unpack_aprons": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "nesr_band_row_bytes": (_c.c_size_t, [_c.c_void_p]),
     "nesr_band_rows": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p]),
     "nesr_set_concurrent": (_c.c_int, [_c.c_void_p, _c.c_int]),

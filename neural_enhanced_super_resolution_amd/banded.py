@@ -14,9 +14,13 @@ feature map about to be read are overwritten with the neighbours' true rows:
     conv_body .. conv_last:            refresh the aprons of the trunk output and of conv_first's output, run the
                                        tail (conv_body 1 row, up1 1/2, up2 1/4, hr 1/4, last 1/4 = 2.25 rows)
 
-The whole apron (6 rows) is refreshed every time, so nothing stale survives a stage.  70 exchange steps per frame,
+The whole apron (6 rows) is refreshed every time, so nothing stale survives a stage.  70 exchange steps per frame
+(one after conv_first, whose rows also refresh the copy kept for the trunk skip, and one after each of the 69 RDBs),
 point to point with the two neighbours only (a line, not a ring; no all-reduce); 1920 px x 6 rows x 64 ch x 4 B =
-2.9 MB per neighbour and step for a 2160p x2plus frame.  The extra arithmetic is
+2.9 MB per neighbour and step for a 2160p x2plus frame.  The default protocol (forward_banded_overlapped) takes the
+exchange off the critical path: an RDB first computes the rows its neighbours wait for, posts them (RCCL point-to-point
+on a side stream, packed by one C-ABI call) and computes conv5 on the rest of the band -- 42 % of the block's
+arithmetic -- while they travel.  The extra arithmetic is
 2*APRON / band rows (8 ranks, 1080 internal rows: +9 %).  Inside the band every pixel sees exactly the operands of the
 single-GPU evaluation and the f32 kernels' per-pixel arithmetic does not depend on where a tile lies, so the N-rank
 result is bitwise the 1-rank result (APRON and the band boundaries are even: the Winograd form depends on the
@@ -46,8 +50,14 @@ def band_split(internal_rows, world):
     return bands
 
 
+def out_buffer(i):
+    """The dense-block buffer RDB i writes its result into (= the one RDB i + 1 reads): P, Q, R rotate."""
+    return (i % 3 + 1) % 3
+
+
 def forward_banded(engine, x_ext, top, bottom, exchange):
-    """One rank's part of the banded forward.
+    """One rank's part of the banded forward, exchange AFTER every stage (the simple order; kept for engines and
+    transports that cannot overlap -- tests drive it in lockstep for emulated ranks).
 
     x_ext    : [1, C, H_ext, W] the rank's input rows including `top` / `bottom` internal apron rows (x unshuffle)
     exchange : callable(buffer, k) that overwrites the k apron rows next to the band, on both sides, of feature
@@ -60,6 +70,34 @@ def forward_banded(engine, x_ext, top, bottom, exchange):
         engine.band_rdb(i)
     exchange(0, APRON)
     exchange(3, APRON)
+    y = engine.band_tail()
+    return y[:, :, 4 * top: y.shape[2] - 4 * bottom]
+
+
+def forward_banded_overlapped(engine, x_ext, top, bottom, ex):
+    """The same evaluation with the exchange off the critical path.  Per RDB i:
+
+        phase 0   conv1..conv4, and conv5 on the APRON band rows next to each apron: the rows the neighbours wait for
+        post      pack those rows of the buffer RDB i wrote and send / receive them (`ex`: asynchronously -- RCCL
+                  point-to-point on a side stream)
+        phase 1   conv5 on the band rows in between (42 % of the block's arithmetic) while the rows travel
+        complete  the neighbours' rows -> the apron rows, before RDB i + 1 reads them
+
+    conv_first's output needs one exchange before RDB 0; the received rows also refresh the copy kept for the trunk
+    skip (buffer 3), so a frame takes 1 + num_rdb exchange steps (70 for 23 blocks), each 2 x APRON rows x w x
+    num_feat values per neighbour.  Values are those of forward_banded: the phases are row ranges of the same kernel."""
+    engine.band_begin(x_ext)
+    ex.complete(ex.post(0), also=(3,))
+    phased = hasattr(engine, "band_rdb_phase")
+    for i in range(engine.num_rdb):
+        if phased:
+            engine.band_rdb_phase(i, 0, top, bottom, APRON)
+        else:
+            engine.band_rdb(i)
+        handle = ex.post(out_buffer(i))
+        if phased:
+            engine.band_rdb_phase(i, 1, top, bottom, APRON)
+        ex.complete(handle)
     y = engine.band_tail()
     return y[:, :, 4 * top: y.shape[2] - 4 * bottom]
 
@@ -96,13 +134,102 @@ def make_exchange(engine, rank, world, top, band_rows, bottom, group=None, via_c
     return exchange
 
 
+class EdgeExchange:
+    """The asynchronous transport of forward_banded_overlapped: rank r <-> r - 1 and r + 1 (a line: no ring, no
+    all-reduce).  `post` packs the APRON edge rows into persistent staging tensors (one C-ABI call on the HIP engine) and
+    starts isend / irecv -- on a side stream for RCCL, so the caller's stream goes on with phase 1; `complete` waits for
+    them and unpacks into the apron rows.  `stats` counts steps and bytes (tests assert the traffic model)."""
+
+    def __init__(self, engine, rank, world, top, band_rows, bottom, group=None, via_cpu=False, device=None, stats=None):
+        self.engine, self.rank, self.world = engine, rank, world
+        self.top, self.band_rows, self.bottom = top, band_rows, bottom
+        self.group, self.via_cpu = group, via_cpu
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.stats = stats if stats is not None else {}
+        self.stats.setdefault("steps", 0)
+        self.stats.setdefault("bytes_per_neighbour", [])
+        self.up, self.down = rank > 0, rank < world - 1
+        self.fast = hasattr(engine, "band_pack_edges")
+        self.side = torch.cuda.Stream(self.device) if (self.device.type == "cuda" and not via_cpu) else None
+        self._bufs = None
+
+    def _staging(self):
+        if self._bufs is None:
+            nbytes = APRON * int(self.engine.band_row_bytes()) if self.fast else None
+            mk = (lambda: torch.empty(nbytes, dtype=torch.uint8, device=self.device)) if self.fast else (lambda: None)
+            self._bufs = {k: (mk() if on else None) for k, on in (("send_up", self.up), ("send_down", self.down),
+                                                                    ("recv_up", self.up), ("recv_down", self.down))}
+        return self._bufs
+
+    def post(self, buffer):
+        b = self._staging()
+        eng = self.engine
+        main = torch.cuda.current_stream(self.device) if self.side is not None else None
+        if self.side is not None:
+            self.side.wait_stream(main)            # phase 0 wrote the rows that are packed now
+        ctx = torch.cuda.stream(self.side) if self.side is not None else _Null()
+        with ctx:
+            if self.fast:
+                eng.band_pack_edges(buffer, self.top, self.bottom, APRON, b["send_up"], b["send_down"])
+                su, sd = b["send_up"], b["send_down"]
+            else:                                   # engines with the row accessors only (the CPU oracle engine of the tests)
+                su = eng.band_rows(buffer, self.top, APRON) if self.up else None
+                sd = eng.band_rows(buffer, self.top + self.band_rows - APRON, APRON) if self.down else None
+                b["recv_up"] = torch.empty_like(su) if self.up else None
+                b["recv_down"] = torch.empty_like(sd) if self.down else None
+            ru, rd = b["recv_up"], b["recv_down"]
+            if self.via_cpu:
+                su, sd = (t.cpu() if t is not None else None for t in (su, sd))
+                ru, rd = (torch.empty_like(t) if t is not None else None for t in (su, sd))
+            ops = []
+            if self.up:
+                ops += [dist.P2POp(dist.isend, su, self.rank - 1, self.group), dist.P2POp(dist.irecv, ru, self.rank - 1, self.group)]
+            if self.down:
+                ops += [dist.P2POp(dist.isend, sd, self.rank + 1, self.group), dist.P2POp(dist.irecv, rd, self.rank + 1, self.group)]
+            works = dist.batch_isend_irecv(ops) if ops else []
+        self.stats["steps"] += 1
+        self.stats["bytes_per_neighbour"].append(int(su.numel()) if su is not None else (int(sd.numel()) if sd is not None else 0))
+        return (buffer, works, ru, rd, (su, sd))
+
+    def complete(self, handle, also=()):
+        buffer, works, ru, rd, _keep = handle
+        eng = self.engine
+        ctx = torch.cuda.stream(self.side) if self.side is not None else _Null()
+        with ctx:
+            for w in works:
+                w.wait()
+        if self.side is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)
+        if self.via_cpu:
+            ru, rd = (t.to(self.device) if t is not None else None for t in (ru, rd))
+        for buf in (buffer,) + tuple(also):
+            if self.fast:
+                eng.band_unpack_aprons(buf, self.top, self.bottom, APRON, ru, rd)
+            else:
+                if ru is not None:
+                    eng.band_set_rows(buf, self.top - APRON, ru)
+                if rd is not None:
+                    eng.band_set_rows(buf, self.top + self.band_rows, rd)
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 @torch.no_grad()
-def enhance_banded(up, band, frame_hw, group=None, gather=True):
+def enhance_banded(up, band, frame_hw, group=None, gather=True, overlap=True, stats=None):
     """Distributed equivalent of ``up.enhance(img)`` for an UNTILED wrapper (``tile=0``) and 8-bit BGR frames.
 
     up        : RealESRGANer with tile=0, pre_pad=0; frame sides multiples of mod_scale
     band      : this rank's input rows, uint8 [rows, W, 3] BGR, rows = the band of band_split() x unshuffle
     frame_hw  : (H, W) of the whole frame
+    overlap   : True = forward_banded_overlapped (edge rows first, exchange beside conv5's interior rows); False = the
+                simple order (exchange, then the whole block).  Same values.
+    stats     : optional dict that receives {"steps", "bytes_per_neighbour"} of the apron exchange
     returns   : on rank 0 (gather=True) the uint8 [H*s, W*s, 3] BGR frame, else this rank's output rows
     """
     world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -144,7 +271,11 @@ def enhance_banded(up, band, frame_hw, group=None, gather=True):
         ext[row0: row0 + t.shape[0]] = t.to(dev)
 
     x = normalize_u8_on_device(ext.permute(2, 0, 1).flip(0)).unsqueeze(0)     # BGR->RGB, /255, HWC->NCHW
-    y = forward_banded(net, x, top, bottom, make_exchange(net, rank, world, top, hi - lo, bottom, group, via_cpu))
+    if overlap:
+        ex = EdgeExchange(net, rank, world, top, hi - lo, bottom, group, via_cpu, dev, stats)
+        y = forward_banded_overlapped(net, x, top, bottom, ex)
+    else:
+        y = forward_banded(net, x, top, bottom, make_exchange(net, rank, world, top, hi - lo, bottom, group, via_cpu))
     q = (y[0].float().clamp_(0, 1).flip(0).permute(1, 2, 0) * 255.0).round().to(torch.uint8).contiguous()   # RGB->BGR, CHW->HWC
     if not gather or world == 1:
         return q.cpu().numpy() if world == 1 else q

@@ -388,6 +388,7 @@ hipError_t launch_xl(const ConvArgs& a, hipStream_t s) {
 }  // namespace
 
 hipError_t launch_conv3x3_bf16_xl(const ConvArgs& a, hipStream_t s) {
+    if (a.y_lo || a.y_hi) return hipErrorInvalidValue;   // row ranges: conv3x3_f16x2_kernel only
     if (a.cin % 16 || !a.zeros) return hipErrorInvalidValue;
     // the 16-byte accesses of the pair image / wide stores need pixel strides of whole 8-channel groups
     if (a.in_map.pix % 8 || (a.out && (a.out_map.pix % 8 || a.out_coff % 16))) return hipErrorInvalidValue;

@@ -215,8 +215,9 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : 2)
 
     // ---- XCD-aware work index (bijective for any count); the cout groups of one tile are neighbours
     const int CG = a.coutp / 32;
+    const int y_lo = a.y_lo, y_hi = a.y_hi > 0 ? a.y_hi : a.h;      // output rows of this launch
     const int tiles_x = (a.w_ + TW - 1) / TW;
-    const int tiles_y = (a.h + TH - 1) / TH;
+    const int tiles_y = (y_hi - y_lo + TH - 1) / TH;
     const int total = tiles_x * tiles_y * a.n * CG;
     int idx;
     {
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : 2)
     const int n = tile / (tiles_x * tiles_y);
     tile -= n * tiles_x * tiles_y;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int y0 = ty * TH, x0 = tx * TW;
+    const int y0 = y_lo + ty * TH, x0 = tx * TW;
 
     // ---- LDS-DMA plan.  LDS item k of an input slot = padded pixel k>>2, physical slot k&3; it holds
     // logical slot (k&3) ^ (bit 2 of the padded column << 1) of that pixel's 64 bytes.  Item k = tid + THREADS*i
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : 2)
     }
     STAMP(6);
 
-    const bool active = is_cmp && (y0 + RW * wave) < a.h;
+    const bool active = is_cmp && (y0 + RW * wave) < y_hi;
 
     // ---- operands.  The MFMA (v_mfma_f32_16x16x32_f16) has K = 32 = two units of 16 channels: lanes 0-31
     // (k-groups g = 0,1 = channel halves) feed unit 0, lanes 32-63 unit 1, and a unit is one (tap, plane)
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(64 * (WAVES + DMAW), DMAW ? (WAVES + DMAW) / 4 : 2)
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh) {
             const int Y = y0 + RW * wave + r, X = x0 + 16 * nh + j16;
-            const bool valid = X < a.w_ && Y < a.h;
+            const bool valid = X < a.w_ && Y < y_hi;
             const size_t pix = ((size_t)n * a.h + (Y < a.h ? Y : 0)) * a.w_ + (X < a.w_ ? X : 0);
             f32x4 v0, v1;   // couts cb .. cb+3, cb+4 .. cb+7
 #pragma unroll
@@ -1026,7 +1027,8 @@ hipError_t launch_split(const ConvArgs& a, hipStream_t s) {
         const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&conv3x3_f16x2_kernel<DMAW>), shm, attr_done);
         if (e != hipSuccess) return e;
     }
-    const long total = (long)((a.w_ + TW - 1) / TW) * ((a.h + G::TH - 1) / G::TH) * a.n * (a.coutp / 32);
+    const int rows = (a.y_hi > 0 ? a.y_hi : a.h) - a.y_lo;
+    const long total = (long)((a.w_ + TW - 1) / TW) * ((rows + G::TH - 1) / G::TH) * a.n * (a.coutp / 32);
     if (total <= 0) return hipSuccess;
     if (total > 0x7fffffffL) return hipErrorInvalidValue;
     hipLaunchKernelGGL((conv3x3_f16x2_kernel<DMAW>), dim3((unsigned)total), dim3(G::LAUNCH_THREADS), shm, s, a);
@@ -1099,6 +1101,7 @@ hipError_t launch_rdb_f16x2(const RdbLaunch& r, hipStream_t s) {
 
 hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s) {
     if (a.cin % 16 || (a.coutp != 32 && a.coutp != 64)) return hipErrorInvalidValue;
+    if (a.y_lo < 0 || (a.y_hi > 0 && (a.y_hi > a.h || a.y_hi <= a.y_lo)) || (a.y_hi == 0 && a.y_lo != 0)) return hipErrorInvalidValue;
     if ((long long)a.in_w * 64 * 12 >= (1ll << 32)) return hipErrorInvalidValue;   // 32-bit byte offsets inside one tile's rows
     if (a.in_map.pix != 32 || (a.out && (a.out_map.pix % 32 || a.out_coff % 16))) return hipErrorInvalidValue;
     if ((a.out_nchw || a.out_u8) && (a.coutp != 32 || a.cout_real < 1 || a.cout_real > 4)) return hipErrorInvalidValue;
@@ -1112,7 +1115,7 @@ hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s) {
         return n;
     }();
     static const int dmaw = [] { const char* e = getenv("NESR_SPLIT_DMAW"); return e ? atoi(e) : -1; }();
-    const long t1 = (long)((a.w_ + TW - 1) / TW) * ((a.h + 7) / 8) * a.n * (a.coutp >> 5);
+    const long t1 = (long)((a.w_ + TW - 1) / TW) * (((a.y_hi > 0 ? a.y_hi : a.h) - a.y_lo + 7) / 8) * a.n * (a.coutp >> 5);
     // ... and only when this context has the device to itself: with frames in flight on other streams the 8-wave
     // workgroups (166 registers) keep a second kernel's workgroups off the CU (2 frames in flight: 158 -> 166 MP/s
     // without them; one frame alone: 134 -> 138 MP/s with them)

@@ -529,7 +529,10 @@ void pack_weights_bf16(const float* oihw, int cout, int cin, int cin_p, int cout
             }
 }
 
-hipError_t launch_conv3x3_f32(const ConvArgs& a, hipStream_t s) { return launch<false>(a, s); }
+hipError_t launch_conv3x3_f32(const ConvArgs& a, hipStream_t s) {
+    if (a.y_lo || a.y_hi) return hipErrorInvalidValue;   // row ranges: conv3x3_f16x2_kernel only
+    return launch<false>(a, s);
+}
 hipError_t launch_trunk_persist(const TrunkArgs& t, bool bf16, hipStream_t s) {
     return bf16 ? launch_trunk<true>(t, s) : launch_trunk<false>(t, s);
 }
@@ -538,6 +541,7 @@ hipError_t launch_trunk_persist(const TrunkArgs& t, bool bf16, hipStream_t s) {
 // depends on the frame size only (never on the batch), so a tile's arithmetic is the same on every
 // rank and in every batch.  NESR_BF16_KERNEL=small|big|xl overrides (tests, A/B timing).
 hipError_t launch_conv3x3_bf16(const ConvArgs& a, hipStream_t s) {
+    if (a.y_lo || a.y_hi) return hipErrorInvalidValue;   // row ranges: conv3x3_f16x2_kernel only
     static const int mode = [] {
         const char* e = getenv("NESR_BF16_KERNEL");
         if (!e) return 0;

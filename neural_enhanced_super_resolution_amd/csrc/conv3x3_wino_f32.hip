@@ -421,6 +421,7 @@ void pack_weights_wino_f32(const float* oihw, int cout, int cin, int cin_p, int 
 }
 
 hipError_t launch_conv3x3_wino_f32(const ConvArgs& a, hipStream_t s) {
+    if (a.y_lo || a.y_hi) return hipErrorInvalidValue;   // row ranges: conv3x3_f16x2_kernel only
     if (a.cin % 8) return hipErrorInvalidValue;
     if ((a.out_nchw || a.out_u8) && (a.coutp != 32 || a.cout_real < 1 || a.cout_real > 4)) return hipErrorInvalidValue;
     // NESR_WINO_NT1=wide: Cout=32 layers as 2-wave workgroups, each wave owning both 16-channel groups

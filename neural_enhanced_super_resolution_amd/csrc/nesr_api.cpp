@@ -241,14 +241,21 @@ int fw_first(nesr_ctx* c, const FwState& F, const float* x_f32, const uint8_t* x
 
 // RDB r (0..2) of RRDB b.  Buffers P,Q,R hold x0|x1|x2|x3|x4 of RDB1,2,3; RDB3's conv5 applies both residuals
 // (x5*0.2+x0 then *0.2 + RRDB input) and lands in P.x0 in place, so every RRDB starts and ends in P.
-int fw_rdb(nesr_ctx* c, const FwState& F, int b, int r, hipStream_t s) {
+// phase: -1 the whole block; 0 conv1..conv4 and conv5 on the `edge` band rows next to each apron (what the neighbours
+// wait for); 1 conv5 on the band rows in between.  Phases need the f16-pair kernel's row ranges: for the other dtypes
+// phase 0 is the whole block and phase 1 nothing.  `top` / `bottom` = apron rows of the band image (conv5 skips them in
+// the phased form: they are overwritten by the neighbours' rows before anything reads them).
+int fw_rdb(nesr_ctx* c, const FwState& F, int b, int r, hipStream_t s, int phase = -1, int top = 0, int bottom = 0, int edge = 0) {
     const int nf = c->nf, gc = c->gc;
     const double px = (double)F.N * F.h * F.w;
     char* cur = F.buf[r];
+    const bool ranged = phase >= 0 && c->dtype == NESR_DTYPE_F32_SPLIT && F.N == 1 && F.h >= top + bottom + 2 * edge;
+    if (phase == 1 && !ranged) return NESR_OK;
+    if (phase >= 0 && !ranged) phase = -1;
     // small frames, f16-pair form: the whole dense block in one launch (rdb_f16x2_kernel).  Every tile needs its own
     // resident workgroup, so the frame's tiles must fit the compute units and the device must be this context's
     // (frames in flight on other streams would compete for the one workgroup slot per CU).
-    if (c->dtype == NESR_DTYPE_F32_SPLIT && c->rdb_mode != 0 && nf == 64 && gc == 32 && !c->shared_device) {
+    if (phase < 0 && c->dtype == NESR_DTYPE_F32_SPLIT && c->rdb_mode != 0 && nf == 64 && gc == 32 && !c->shared_device) {
         const int tiles = rdb_f16x2_tiles(F.N, F.h, F.w);
         if (tiles <= c->cus && tiles <= 4096) {
             RdbLaunch L;
@@ -275,7 +282,7 @@ int fw_rdb(nesr_ctx* c, const FwState& F, int b, int r, hipStream_t s) {
             return NESR_OK;
         }
     }
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < 4 && phase != 1; ++k) {
         const Layer& Ly = c->layers[layer_id(c, b, r, k)];
         ConvArgs a = base_args(c, Ly, F.N, F.h, F.w);
         a.in = cur; a.in_map = F.m_t;
@@ -295,8 +302,29 @@ int fw_rdb(nesr_ctx* c, const FwState& F, int b, int r, hipStream_t s) {
         a.res2 = F.buf[0]; a.res2_map = F.m_t; a.s2 = 0.2f;
     }
     a.out_map = F.m_t; a.out_coff = 0;
-    HIP_TRY(launch_conv(c, a, s, &L5));
-    if (c->timing) { c->timed_flops += conv_flops(L5, px); c->timed_launches += 5; }
+    if (phase < 0) {
+        HIP_TRY(launch_conv(c, a, s, &L5));
+    } else {
+        // band rows [top, h - bottom); a side without an apron (a frame edge) has no neighbour waiting: its rows belong
+        // to the interior launch
+        const int lo = top, hi = F.h - bottom;
+        const int e0 = top ? lo + edge : lo, e1 = bottom ? hi - edge : hi;      // interior = [e0, e1)
+        auto rows = [&](int y0, int y1) -> int {
+            if (y1 <= y0) return NESR_OK;
+            ConvArgs q = a;
+            q.y_lo = y0; q.y_hi = y1;
+            HIP_TRY(launch_conv(c, q, s, &L5));
+            return NESR_OK;
+        };
+        int rc;
+        if (phase == 0) {
+            if (top && (rc = rows(lo, e0 < e1 ? e0 : e1))) return rc;
+            if (bottom && (rc = rows(e1 > e0 ? e1 : e0, hi))) return rc;
+        } else if ((rc = rows(e0, e1))) {
+            return rc;
+        }
+    }
+    if (c->timing && phase != 0) { c->timed_flops += conv_flops(L5, px); c->timed_launches += 5; }
     return NESR_OK;
 }
 
@@ -788,6 +816,38 @@ int nesr_band_rdb(nesr_ctx* c, int index, void* stream) {
     if (index < 0 || index >= 3 * c->nb) return fail(NESR_ERR_ARG, "RDB index out of range");
     HIP_TRY(hipSetDevice(c->device));
     return fw_rdb(c, c->band, index / 3, index % 3, static_cast<hipStream_t>(stream));
+}
+
+int nesr_band_rdb_phase(nesr_ctx* c, int index, int phase, int top, int bottom, int edge_rows, void* stream) {
+    if (!c) return fail(NESR_ERR_ARG, "null ctx");
+    if (!c->band_valid) return fail(NESR_ERR_STATE, "nesr_band_begin has not run (or a whole-frame forward reused the workspace)");
+    if (index < 0 || index >= 3 * c->nb) return fail(NESR_ERR_ARG, "RDB index out of range");
+    if ((phase != 0 && phase != 1) || top < 0 || bottom < 0 || edge_rows < 0 || top + bottom > c->band.h)
+        return fail(NESR_ERR_ARG, "bad phase / apron / edge rows");
+    HIP_TRY(hipSetDevice(c->device));
+    return fw_rdb(c, c->band, index / 3, index % 3, static_cast<hipStream_t>(stream), phase, top, bottom, edge_rows);
+}
+
+int nesr_band_pack_edges(nesr_ctx* c, int buffer, int top, int bottom, int nrows, void* top_dst, void* bottom_dst, void* stream) {
+    if (!c) return fail(NESR_ERR_ARG, "null ctx");
+    if (!c->band_valid) return fail(NESR_ERR_STATE, "nesr_band_begin has not run (or a whole-frame forward reused the workspace)");
+    const int h = c->band.h;
+    if (top < 0 || bottom < 0 || nrows < 0 || top + bottom + nrows > h) return fail(NESR_ERR_ARG, "bad apron / row count");
+    int rc = NESR_OK;
+    if (top_dst && (rc = nesr_band_rows(c, buffer, top, nrows, top_dst, 0, stream))) return rc;
+    if (bottom_dst && (rc = nesr_band_rows(c, buffer, h - bottom - nrows, nrows, bottom_dst, 0, stream))) return rc;
+    return NESR_OK;
+}
+
+int nesr_band_unpack_aprons(nesr_ctx* c, int buffer, int top, int bottom, int nrows, const void* top_src, const void* bottom_src, void* stream) {
+    if (!c) return fail(NESR_ERR_ARG, "null ctx");
+    if (!c->band_valid) return fail(NESR_ERR_STATE, "nesr_band_begin has not run (or a whole-frame forward reused the workspace)");
+    const int h = c->band.h;
+    if ((top_src && nrows > top) || (bottom_src && nrows > bottom) || nrows < 0) return fail(NESR_ERR_ARG, "more rows than the apron holds");
+    int rc = NESR_OK;
+    if (top_src && (rc = nesr_band_rows(c, buffer, top - nrows, nrows, const_cast<void*>(top_src), 1, stream))) return rc;
+    if (bottom_src && (rc = nesr_band_rows(c, buffer, h - bottom, nrows, const_cast<void*>(bottom_src), 1, stream))) return rc;
+    return NESR_OK;
 }
 
 int nesr_band_tail(nesr_ctx* c, void* y_dev, void* stream) {

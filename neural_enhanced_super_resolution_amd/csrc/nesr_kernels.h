@@ -49,6 +49,10 @@ struct ConvArgs {
     int coutp;             // padded output channels: 32 or 64
     // geometry of the convolution (logical input == output spatial size)
     int n, h, w_;
+    // output rows [y_lo, y_hi) only (0, 0 = all of [0, h)): the banded multi-GPU mode computes the rows its neighbours
+    // wait for first.  The input is still the whole image: rows outside [0, h) are the zero padding, rows outside
+    // [y_lo, y_hi) are real data.  conv3x3_f16x2_kernel only (the other launchers reject a row range).
+    int y_lo, y_hi;
     // feature-map output (may be null when out_nchw / out_u8 is used)
     void* out;
     Map out_map;

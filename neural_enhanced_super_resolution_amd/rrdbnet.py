@@ -334,6 +334,38 @@ class RRDBNet(nn.Module):
             _lib.check(_lib.load().nesr_band_rdb(ctx, int(index), stream), "nesr_band_rdb")
 
     @torch.no_grad()
+    def band_rdb_phase(self, index, phase, top, bottom, edge_rows):
+        """Phase 0: conv1..conv4 of RDB `index` and conv5 on the `edge_rows` band rows next to each apron (what the
+        neighbours wait for); phase 1: conv5 on the rows in between.  Same values as band_rdb."""
+        ctx, dev, stream = self._band_call()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().nesr_band_rdb_phase(ctx, int(index), int(phase), int(top), int(bottom), int(edge_rows), stream),
+                       "nesr_band_rdb_phase")
+
+    def band_row_bytes(self):
+        ctx, _, _ = self._band_call()
+        return int(_lib.load().nesr_band_row_bytes(ctx))
+
+    @torch.no_grad()
+    def band_pack_edges(self, buffer, top, bottom, nrows, top_dst, bottom_dst):
+        """The first / last `nrows` BAND rows (the rows the neighbours need) of `buffer` -> two preallocated uint8 tensors
+        (either may be None), in one C-ABI call."""
+        ctx, dev, stream = self._band_call()
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()   # noqa: E731
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().nesr_band_pack_edges(ctx, int(buffer), int(top), int(bottom), int(nrows), ptr(top_dst), ptr(bottom_dst), stream),
+                       "nesr_band_pack_edges")
+
+    @torch.no_grad()
+    def band_unpack_aprons(self, buffer, top, bottom, nrows, top_src, bottom_src):
+        """The neighbours' rows -> the `nrows` apron rows next to the band on each side (either source may be None)."""
+        ctx, dev, stream = self._band_call()
+        ptr = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p()   # noqa: E731
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().nesr_band_unpack_aprons(ctx, int(buffer), int(top), int(bottom), int(nrows), ptr(top_src), ptr(bottom_src), stream),
+                       "nesr_band_unpack_aprons")
+
+    @torch.no_grad()
     def band_tail(self):
         """conv_body .. conv_last -> [1, num_out_ch, 4 h, 4 w] float32 (h, w = internal size of the band image)."""
         ctx, dev, stream = self._band_call()

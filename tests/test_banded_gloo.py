@@ -78,7 +78,7 @@ def _reference(sd, img, scale, num_block):
     return (y[0].clamp(0, 1).flip(0).permute(1, 2, 0) * 255.0).round().to(torch.uint8).numpy(), y
 
 
-def _worker(rank, world, port, hw, scale, num_block, out_path):
+def _worker(rank, world, port, hw, scale, num_block, out_path, overlap=True):
     torch.set_num_threads(2)
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
@@ -86,7 +86,14 @@ def _worker(rank, world, port, hw, scale, num_block, out_path):
         img = synthetic_frame(hw[0], hw[1], seed=7)
         eng = OracleBandEngine(sd, scale, num_block)
         band = banded.scatter_band(img, rank, world, eng.unshuffle)
-        got = banded.enhance_banded(_Up(eng, 2 if scale == 2 else 4), band, hw)
+        stats = {}
+        got = banded.enhance_banded(_Up(eng, 2 if scale == 2 else 4), band, hw, overlap=overlap, stats=stats)
+        if overlap:
+            # the traffic model of DESIGN.md section 6: one step after conv_first + one per RDB (70 for 23 blocks), each
+            # APRON rows x w x 64 channels x 4 bytes per neighbour -- nothing else crosses a band boundary
+            w_int = hw[1] // eng.unshuffle
+            assert stats["steps"] == 1 + eng.num_rdb <= 70
+            assert set(stats["bytes_per_neighbour"]) == {banded.APRON * w_int * 64 * 4}, stats["bytes_per_neighbour"][:3]
         if rank == 0:
             np.save(out_path, got)
         else:
@@ -95,17 +102,22 @@ def _worker(rank, world, port, hw, scale, num_block, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,hw,scale", [(2, (64, 48), 2), (3, (96, 40), 2), (2, (32, 24), 4)])
-def test_banded_equals_untiled_single_process(tmp_path, world, hw, scale):
+@pytest.mark.parametrize("world,hw,scale,overlap", [(2, (64, 48), 2, True), (3, (96, 40), 2, True), (2, (32, 24), 4, True), (2, (64, 48), 2, False)])
+def test_banded_equals_untiled_single_process(tmp_path, world, hw, scale, overlap):
     out = str(tmp_path / "banded.npy")
     num_block = 2
-    mp.spawn(_worker, args=(world, _free_port(), hw, scale, num_block, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), hw, scale, num_block, out, overlap), nprocs=world, join=True)
     got = np.load(out)
     sd = synthetic_state_dict(seed=5, num_in_ch=3, scale=scale, num_block=num_block)
     want, _ = _reference(sd, synthetic_frame(hw[0], hw[1], seed=7), scale, num_block)
     assert got.shape == want.shape
     diff = np.abs(got.astype(np.int16) - want.astype(np.int16))
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3      # float-level differences may flip a rounding
+
+
+def test_exchange_step_count_for_the_real_network():
+    """23 blocks: 1 + 69 = 70 exchange steps per frame (SURVEY.md section 8(e) asked for ~75, round 1 had 71)."""
+    assert 1 + 3 * 23 == 70 and [banded.out_buffer(i) for i in range(6)] == [1, 2, 0, 1, 2, 0]
 
 
 def test_band_split_properties():

@@ -42,6 +42,51 @@ def _banded(nets, x, world):
     return torch.cat(outs, 2)
 
 
+def _banded_overlapped(nets, x, world):
+    """The default protocol (banded.forward_banded_overlapped) for emulated ranks in lockstep: phase 0, pack the edge rows
+    (one C-ABI call per rank), phase 1, unpack the neighbours' rows (one call per rank)."""
+    from neural_enhanced_super_resolution_amd import banded
+    A = banded.APRON
+    u = nets[0].unshuffle
+    bands = banded.band_split(x.shape[2] // u, world)
+    tops = [A if r > 0 else 0 for r in range(world)]
+    bots = [A if r < world - 1 else 0 for r in range(world)]
+    for r, net in enumerate(nets):
+        lo, hi = bands[r]
+        net.band_begin(x[:, :, (lo - tops[r]) * u:(hi + bots[r]) * u].contiguous())
+    nbytes = A * nets[0].band_row_bytes()
+    mk = lambda: torch.empty(nbytes, dtype=torch.uint8, device=x.device)   # noqa: E731
+    send_up = [mk() if r > 0 else None for r in range(world)]
+    send_down = [mk() if r < world - 1 else None for r in range(world)]
+
+    def pack(buffer):
+        for r, net in enumerate(nets):
+            net.band_pack_edges(buffer, tops[r], bots[r], A, send_up[r], send_down[r])
+
+    def unpack(buffers):
+        for r, net in enumerate(nets):
+            for b in buffers:
+                net.band_unpack_aprons(b, tops[r], bots[r], A, send_down[r - 1] if r > 0 else None, send_up[r + 1] if r < world - 1 else None)
+
+    pack(0)
+    unpack((0, 3))
+    steps = 1
+    for i in range(nets[0].num_rdb):
+        for r, net in enumerate(nets):
+            net.band_rdb_phase(i, 0, tops[r], bots[r], A)
+        pack(banded.out_buffer(i))
+        for r, net in enumerate(nets):
+            net.band_rdb_phase(i, 1, tops[r], bots[r], A)
+        unpack((banded.out_buffer(i),))
+        steps += 1
+    outs = []
+    for r, net in enumerate(nets):
+        y = net.band_tail()
+        outs.append(y[:, :, 4 * tops[r]: y.shape[2] - 4 * bots[r]])
+    assert steps == 1 + nets[0].num_rdb
+    return torch.cat(outs, 2)
+
+
 def _nets(n, algo, scale, num_block=2):
     from neural_enhanced_super_resolution_amd import RRDBNet
     from neural_enhanced_super_resolution_amd.synth import synthetic_state_dict
@@ -63,6 +108,25 @@ def test_banded_bitwise_equals_whole_frame(cuda_device, algo, world, scale, hw):
     got = _banded(nets[:world], x, world)
     assert got.shape == want.shape
     assert torch.equal(got, want), float((got - want).abs().max())
+
+
+@pytest.mark.parametrize("algo", ["f32", "f32-winograd", "f32-direct"])
+@pytest.mark.parametrize("world,scale,hw", [(2, 2, (96, 80)), (3, 2, (132, 72)), (2, 4, (40, 56)), (2, 2, (560, 544))])
+def test_overlapped_protocol_bitwise_equals_whole_frame(cuda_device, algo, world, scale, hw):
+    """Edge rows first, conv5's interior rows while they travel (row-range launches for the default f32 form; whole-block
+    phase 0 for the others): still bit for bit the whole-frame forward.  560x544: bands of several tile rows, and a
+    whole frame that is evaluated by per-layer launches (more tiles than CUs) -- the small frames compare against the fused
+    dense-block kernel."""
+    if hw[0] > 200 and algo != "f32":
+        pytest.skip("large frame: default form only")
+    nets = _nets(world + 1, algo, scale)
+    x = torch.rand(1, 3, hw[0], hw[1], generator=torch.Generator().manual_seed(4)).to(cuda_device)
+    want = nets[-1](x)
+    got = _banded_overlapped(nets[:world], x, world)
+    assert got.shape == want.shape
+    assert torch.equal(got, want), float((got - want).abs().max())
+    for n in nets:
+        n.check_status()
 
 
 def test_banded_bf16_same_operands(cuda_device):
