@@ -213,6 +213,7 @@ def main():
                          "replica); default 4 for c2 / c2-bf16 (2: -5 %%, 1: -20 %%, 6-8: no more), 1 otherwise")
     ap.add_argument("--f32-algo", default=None, choices=["split", "winograd", "direct"],
                     help="conv algorithm of the fp32 workloads (default split: f16 hi+lo operand pairs)")
+    ap.add_argument("--filters", action="store_true", help="c5: also run the reference's cv2 pre / post filters (imgproc.py: NL-means + CLAHE, adaptive unsharp)")
     ap.add_argument("--dry-launch", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -532,7 +533,7 @@ def bench_c5(args, wl, dev, rank, world, timed):
 
     def step():
         trace.clear()
-        last["out"] = nesr_adapter.enhance_iterations(up, img, cfg, "cuda", trace=trace)
+        last["out"] = nesr_adapter.enhance_iterations(up, img, cfg, "cuda", trace=trace, filters=args.filters)
 
     steps = max(1, min(args.steps, 3))
     el = timed(step, steps, min(args.warmup, 1))
@@ -547,7 +548,10 @@ def bench_c5(args, wl, dev, rank, world, timed):
             "dtype": F32_ALGOS["split"]["dtype"], "data": "synthetic (seeded frame, seeded random-init weights)",
             "config": {"workload": f"c5: {wl['desc']}",
                        "routes": [{k: t[k] for k in ("in_shape", "out_shape", "tiled", "three_channel", "model_calls")} for t in trace],
-                       "note": "cv2 pre/post filters off (cv2 is not installed); network evaluations are the reference's, tile for tile"},
+                       "filters": bool(args.filters),
+                       "note": ("with the reference's pre / post filters (NL-means + CLAHE, adaptive unsharp) restated on the device, parity unpinned"
+                                if args.filters else "cv2 pre/post filters off (--filters turns their device-side restatement on)")
+                               + "; network evaluations are the reference's, tile for tile"},
             "tflops_whole_net": round(world * steps * flops / el / 1e12, 1)}), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -16,8 +16,8 @@ processor on a 256x256 corner and discards the result).
 cv2 is not available offline, so its two non-trivial image ops are restated, PARITY UNPINNED:
   * cv2.GaussianBlur(u8, (3,3), 0): kernel [1 2 1]/4 separable, BORDER_REFLECT_101, fixed-point with
     round-half-up -> (S + 8) >> 4 on the 16-weight integer sum.
-  * cv2.resize(..., INTER_LANCZOS4): cv2's coefficient formula (interpolateLanczos4) and sampling
-    geometry, evaluated in float32 (cv2 uses 11-bit fixed-point coefficients: expect +-1 LSB).
+  * cv2.resize(..., INTER_LANCZOS4): cv2's coefficient formula (interpolateLanczos4), sampling geometry and 8-bit
+    fixed point (coefficients x2048 as shorts, integer passes, (v + 2^21) >> 22): imgproc.lanczos4_resize.
 """
 from __future__ import annotations
 
@@ -106,42 +106,7 @@ def apply_esrgan_3channel(upscaler, image_rgb, as_numpy=True):
 
 
 # ----------------------------------------------------------------------------- Lanczos-4 resize
-def _lanczos4_coeffs(frac):
-    """cv2 interpolateLanczos4 for a float32 tensor of fractional offsets -> [..., 8] weights."""
-    s45 = 0.70710678118654752440084436210485
-    cs = torch.tensor([[1, 0], [-s45, -s45], [0, 1], [s45, -s45], [-1, 0], [s45, s45], [0, -1], [-s45, s45]],
-                      dtype=torch.float64, device=frac.device)
-    x = frac.to(torch.float64)
-    y0 = -(x + 3) * (math.pi * 0.25)
-    s0, c0 = torch.sin(y0), torch.cos(y0)
-    i = torch.arange(8, device=frac.device, dtype=torch.float64)
-    y = -(x[..., None] + 3 - i) * (math.pi * 0.25)
-    co = ((cs[:, 0] * s0[..., None] + cs[:, 1] * c0[..., None]) / (y * y)).to(torch.float32)
-    co = co * (1.0 / co.sum(-1, keepdim=True))
-    exact = (frac < 1.1920929e-07)[..., None]
-    delta = torch.zeros(8, device=frac.device)
-    delta[3] = 1.0
-    return torch.where(exact, delta.expand_as(co), co)
-
-
-def lanczos4_resize_u8(img, out_h, out_w):
-    """img uint8 [H, W, C] tensor -> uint8 [out_h, out_w, C]; cv2.resize(INTER_LANCZOS4) geometry."""
-    h, w, c = img.shape
-    x = img.permute(2, 0, 1).float()
-
-    def axis(n_in, n_out):
-        scale = n_in / n_out
-        pos = (torch.arange(n_out, device=img.device, dtype=torch.float32) + 0.5) * scale - 0.5
-        i0 = torch.floor(pos)
-        frac = pos - i0
-        idx = (i0.long()[:, None] + torch.arange(-3, 5, device=img.device)).clamp_(0, n_in - 1)   # replicate border
-        return idx, _lanczos4_coeffs(frac)
-
-    ix, wx = axis(w, out_w)
-    iy, wy = axis(h, out_h)
-    tmp = (x[:, :, ix] * wx).sum(-1)                       # [C, H, out_w]
-    out = (tmp[:, iy, :] * wy[None, :, :, None]).sum(2)    # [C, out_h, out_w]
-    return out.round_().clamp_(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous()
+from .imgproc import lanczos4_resize as lanczos4_resize_u8   # noqa: E402  cv2.resize(INTER_LANCZOS4), OpenCV's 8-bit fixed point
 
 
 # ----------------------------------------------------------------------------- NESR tiler + dispatcher
@@ -236,7 +201,7 @@ def apply_esrgan(upscaler, image_rgb, config=None, device_kind="cuda", as_numpy=
 
 
 def enhance_iterations(upscaler, image_rgb, config=None, device_kind="cuda", preprocess=None, postprocess=None,
-                       trace=None, large_mp=LARGE_IMAGE_MP):
+                       trace=None, large_mp=LARGE_IMAGE_MP, filters=False):
     """The iteration loop of SuperResolutionPipeline.enhance_image (nesr.py:516-633) around its ESRGAN stage:
 
         for iteration in range(config['iterations']):           nesr.py:516
@@ -246,12 +211,17 @@ def enhance_iterations(upscaler, image_rgb, config=None, device_kind="cuda", pre
             current = _postprocess_image(current)                nesr.py:616   -> `postprocess` (adaptive unsharp; None = off)
 
     with diffusion and segmentation off (BASELINE.json configs[4]: `--no_diffusion`; the SegFormer weights are a
-    network fetch).  Frames stay on the GPU between iterations; the final frame is returned as an HWC uint8 RGB
+    network fetch).  `filters=True` runs the reference's cv2 pre / post filters too (NL-means + CLAHE, adaptive unsharp:
+    imgproc.py, OpenCV's algorithms restated -- parity unpinned).  Frames stay on the GPU between iterations; the final frame is returned as an HWC uint8 RGB
     ndarray.  A backend failure raises (the reference would hand back a bicubic resize, nesr.py:835-843); `trace`
     receives one dict per iteration with the route and the number of network evaluations, so a caller can assert
     that the network really ran."""
-    cfg = {"iterations": 3, "upscale_factor": 2.0}
+    cfg = {"iterations": 3, "upscale_factor": 2.0, "denoise_level": 0.5, "adaptive_sharpening": True}
     cfg.update(config or {})
+    if filters:      # the reference's own pre / post filters (nesr.py:668-689, 1056-1084), on the device: imgproc.py (cv2 restated)
+        from . import imgproc
+        preprocess = preprocess or (lambda im: imgproc.preprocess_image(_u8_on(im, upscaler.device), cfg["denoise_level"]))
+        postprocess = postprocess or (lambda im: imgproc.postprocess_image(_u8_on(im, upscaler.device), cfg["adaptive_sharpening"]))
     current = image_rgb
     for iteration in range(int(cfg["iterations"])):
         if preprocess is not None:

@@ -10,8 +10,8 @@
 
 Host logic only (padding, tile grid, cropping, colour order, quantisation); every network
 evaluation goes through ``self.model``, which for this package is the HIP-backed
-:class:`RRDBNet`.  cv2 is optional: the colour conversions are plain numpy; only
-``outscale != scale`` and ``alpha_upsampler != 'realesrgan'`` need cv2.resize.
+:class:`RRDBNet`.  cv2 is not needed: the colour conversions are plain numpy, and ``outscale != scale`` /
+``alpha_upsampler != 'realesrgan'`` use imgproc.py's device-side restatement of cv2.resize (parity unpinned).
 """
 from __future__ import annotations
 
@@ -373,7 +373,7 @@ class RealESRGANer:
         return results
 
     @torch.no_grad()
-    def enhance_float(self, img):
+    def enhance_float(self, img, alpha_upsampler="realesrgan"):
         """Everything of enhance() up to (not including) quantisation: returns (HWC float32 in
         [0,1] in BGR(A)/gray order, img_mode, max_range)."""
         img = img.astype(np.float32)
@@ -389,7 +389,8 @@ class RealESRGANer:
             img_mode = "RGBA"
             alpha = img[:, :, 3]
             img = img[:, :, 0:3][:, :, ::-1]
-            alpha = _gray2rgb(alpha)
+            if alpha_upsampler == "realesrgan":
+                alpha = _gray2rgb(alpha)
         else:
             img_mode = "RGB"
             img = img[:, :, ::-1]
@@ -403,12 +404,18 @@ class RealESRGANer:
             output_img = _bgr2gray(output_img)
 
         if img_mode == "RGBA":
-            self.pre_process(np.ascontiguousarray(alpha))
-            output_alpha = self._run()
-            output_alpha = output_alpha.data.squeeze().float().cpu().clamp_(0, 1).numpy()
-            self._check_range()
-            output_alpha = np.transpose(output_alpha[[2, 1, 0], :, :], (1, 2, 0))
-            output_alpha = _bgr2gray(output_alpha)
+            if alpha_upsampler == "realesrgan":
+                self.pre_process(np.ascontiguousarray(alpha))
+                output_alpha = self._run()
+                output_alpha = output_alpha.data.squeeze().float().cpu().clamp_(0, 1).numpy()
+                self._check_range()
+                output_alpha = np.transpose(output_alpha[[2, 1, 0], :, :], (1, 2, 0))
+                output_alpha = _bgr2gray(output_alpha)
+            else:   # upstream: cv2.resize(alpha, (w * scale, h * scale), interpolation=cv2.INTER_LINEAR)
+                from . import imgproc
+                h, w = alpha.shape[0:2]
+                a = torch.from_numpy(np.ascontiguousarray(alpha)).to(self.device)
+                output_alpha = imgproc.linear_resize_f32(a, h * self.scale, w * self.scale).cpu().numpy()
             output_img = np.concatenate([output_img, output_alpha[:, :, None]], axis=2)
         return output_img, img_mode, max_range
 
@@ -416,10 +423,9 @@ class RealESRGANer:
     def enhance(self, img, outscale=None, alpha_upsampler="realesrgan"):
         """img: HWC uint8/uint16 BGR | BGRA | gray ndarray -> (ndarray of the same kind, upscaled; img_mode)."""
         h_input, w_input = img.shape[0:2]
-        if alpha_upsampler != "realesrgan" and img.ndim == 3 and img.shape[2] == 4:
-            raise NotImplementedError("alpha_upsampler other than 'realesrgan' needs cv2.resize, which is not bundled")
+        plain_alpha = alpha_upsampler != "realesrgan" and img.ndim == 3 and img.shape[2] == 4
 
-        if self._fused_u8_ok(img):
+        if self._fused_u8_ok(img) and not plain_alpha:
             # /255, BGR->RGB, network, clamp, RGB->BGR, x255, round -- all inside the HIP path
             x = torch.from_numpy(np.ascontiguousarray(img)).to(self.device)
             output = self.model.forward_u8(x, flip_rgb=True, round_nearest=True).cpu().numpy()
@@ -429,16 +435,18 @@ class RealESRGANer:
             output = self._enhance_u8_on_device(img)
             img_mode = "RGB"
         else:
-            output_img, img_mode, max_range = self.enhance_float(img)
+            output_img, img_mode, max_range = self.enhance_float(img, alpha_upsampler)
             if max_range == 65535:  # 16-bit image
                 output = (output_img * 65535.0).round().astype(np.uint16)
             else:
                 output = (output_img * 255.0).round().astype(np.uint8)
 
         if outscale is not None and outscale != float(self.scale):
-            try:
-                import cv2
-            except ImportError as e:  # pragma: no cover
-                raise NotImplementedError("outscale != scale needs cv2.resize(INTER_LANCZOS4); cv2 is not installed") from e
-            output = cv2.resize(output, (int(w_input * outscale), int(h_input * outscale)), interpolation=cv2.INTER_LANCZOS4)
+            # upstream: cv2.resize(output, (int(w_input * outscale), int(h_input * outscale)), interpolation=cv2.INTER_LANCZOS4);
+            # here OpenCV's algorithm restated on the device (imgproc.lanczos4_resize: PARITY UNPINNED, cv2 is not installed)
+            from . import imgproc
+            t = torch.from_numpy(np.ascontiguousarray(output if output.dtype == np.uint8 else output.astype(np.int32))).to(self.device)
+            t = t[:, :, None] if t.dim() == 2 else t
+            r = imgproc.lanczos4_resize(t, int(h_input * outscale), int(w_input * outscale)).cpu().numpy().astype(output.dtype)
+            output = r[:, :, 0] if output.ndim == 2 else r
         return output, img_mode

@@ -61,44 +61,10 @@ def apply_3channel(model, image_rgb):
     return np.ascontiguousarray(quantize_trunc_to_rgb(y))
 
 
-def lanczos4_coeffs(x):
-    """OpenCV interpolateLanczos4 (imgproc/src/resize.cpp / imgwarp): 8 weights for fractional offset x."""
-    if x < np.finfo(np.float32).eps:
-        c = np.zeros(8, np.float32)
-        c[3] = 1
-        return c
-    s45 = 0.70710678118654752440084436210485
-    cs = [(1, 0), (-s45, -s45), (0, 1), (s45, -s45), (-1, 0), (s45, s45), (0, -1), (-s45, s45)]
-    y0 = -(x + 3) * math.pi * 0.25
-    s0, c0 = math.sin(y0), math.cos(y0)
-    co = np.zeros(8, np.float32)
-    for i in range(8):
-        y = -(x + 3 - i) * math.pi * 0.25
-        co[i] = np.float32((cs[i][0] * s0 + cs[i][1] * c0) / (y * y))
-    return (co * np.float32(1.0 / co.sum(dtype=np.float32))).astype(np.float32)
-
-
 def lanczos4_resize_u8(img, out_h, out_w):
-    """cv2.resize(img, (out_w, out_h), interpolation=INTER_LANCZOS4) restated in float32."""
-    h, w, c = img.shape
-
-    def axis(n_in, n_out):
-        idx = np.zeros((n_out, 8), np.int64)
-        wts = np.zeros((n_out, 8), np.float32)
-        scale = np.float32(n_in / n_out)
-        for d in range(n_out):
-            pos = np.float32((np.float32(d) + np.float32(0.5)) * scale - np.float32(0.5))
-            i0 = math.floor(pos)
-            wts[d] = lanczos4_coeffs(np.float32(pos - i0))
-            idx[d] = np.clip(np.arange(i0 - 3, i0 + 5), 0, n_in - 1)
-        return idx, wts
-
-    ix, wx = axis(w, out_w)
-    iy, wy = axis(h, out_h)
-    x = img.astype(np.float32)
-    tmp = (x[:, ix, :] * wx[None, :, :, None]).sum(2, dtype=np.float32)          # [H, out_w, C]
-    out = (tmp[iy, :, :] * wy[:, :, None, None]).sum(1, dtype=np.float32)          # [out_h, out_w, C]
-    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+    """cv2.resize(img, (out_w, out_h), interpolation=INTER_LANCZOS4): oracle/cv2_ref.py (OpenCV's 8-bit fixed point)."""
+    from oracle import cv2_ref
+    return cv2_ref.resize_lanczos4(np.ascontiguousarray(img), out_h, out_w)
 
 
 def process_with_tiling(processor, image, tile_size, padding, upscale_factor):
@@ -171,12 +137,19 @@ def apply_esrgan(model, image, config=None, device_kind="cuda", large_mp=16, tra
     return proc(image)                                                             # nesr.py:810-813
 
 
-def enhance_iterations(model, image, config=None, device_kind="cuda", large_mp=16, trace=None):
-    """nesr.py:516-633 with use_diffusion=False, segment_enhancement=False and the cv2 pre/post filters off:
-    per iteration current = _ensemble_results([_apply_esrgan(current)]) = _apply_esrgan(current) (nesr.py:1035-1036)."""
-    cfg = {"iterations": 3, "upscale_factor": 2.0}
+def enhance_iterations(model, image, config=None, device_kind="cuda", large_mp=16, trace=None, filters=False):
+    """nesr.py:516-633 with use_diffusion=False, segment_enhancement=False: per iteration
+    current = _postprocess_image(_ensemble_results([_apply_esrgan(_preprocess_image(current))])), the ensemble of one model
+    being the identity (nesr.py:1035-1036); filters=False leaves the cv2 pre / post filters (oracle/cv2_ref.py) out."""
+    cfg = {"iterations": 3, "upscale_factor": 2.0, "denoise_level": 0.5, "adaptive_sharpening": True}
     cfg.update(config or {})
     current = image
     for _ in range(int(cfg["iterations"])):
+        if filters:
+            from oracle import cv2_ref
+            current = cv2_ref.preprocess_image(current, cfg["denoise_level"])
         current = apply_esrgan(model, current, cfg, device_kind, large_mp, trace)
+        if filters:
+            from oracle import cv2_ref
+            current = cv2_ref.postprocess_image(current, cfg["adaptive_sharpening"])
     return current

@@ -137,7 +137,7 @@ class RealESRGANerRef:
         return self.post_process()
 
     @torch.no_grad()
-    def enhance_float(self, img):
+    def enhance_float(self, img, alpha_upsampler="realesrgan"):
         """The float image upstream enhance() holds just before quantisation (HWC, BGR order,
         clamped to [0,1]) -- what the 1e-3 criterion is measured on."""
         img = img.astype(np.float32)
@@ -150,7 +150,8 @@ class RealESRGANerRef:
             img_mode = "RGBA"
             alpha = img[:, :, 3]
             img = img[:, :, 0:3][:, :, ::-1]                      # COLOR_BGR2RGB
-            alpha = np.repeat(alpha[:, :, None], 3, axis=2)       # COLOR_GRAY2RGB
+            if alpha_upsampler == "realesrgan":
+                alpha = np.repeat(alpha[:, :, None], 3, axis=2)   # COLOR_GRAY2RGB
         else:
             img_mode = "RGB"
             img = img[:, :, ::-1]                                 # COLOR_BGR2RGB
@@ -159,7 +160,12 @@ class RealESRGANerRef:
         out = np.transpose(out[[2, 1, 0], :, :], (1, 2, 0))
         if img_mode == "L":
             out = bgr2gray_f32(out)
-        if img_mode == "RGBA":
+        if img_mode == "RGBA" and alpha_upsampler != "realesrgan":
+            from oracle import cv2_ref
+            h, w = alpha.shape[0:2]
+            oa = cv2_ref.resize_linear_f32(np.ascontiguousarray(alpha), h * self.scale, w * self.scale)   # cv2.resize(alpha, ..., INTER_LINEAR)
+            out = np.concatenate([out, oa[:, :, None]], axis=2)
+        elif img_mode == "RGBA":
             self.pre_process(np.ascontiguousarray(alpha))
             oa = self._run().data.squeeze().float().cpu().clamp_(0, 1).numpy()
             oa = bgr2gray_f32(np.transpose(oa[[2, 1, 0], :, :], (1, 2, 0)))
@@ -168,13 +174,15 @@ class RealESRGANerRef:
 
     @torch.no_grad()
     def enhance(self, img, outscale=None, alpha_upsampler="realesrgan"):
-        if alpha_upsampler != "realesrgan":
-            raise NotImplementedError("oracle: cv2.resize alpha path not restated (cv2 absent)")
-        out, img_mode, max_range = self.enhance_float(img)
+        h_input, w_input = img.shape[0:2]
+        out, img_mode, max_range = self.enhance_float(img, alpha_upsampler)
         if max_range == 65535:
             output = (out * 65535.0).round().astype(np.uint16)
         else:
             output = (out * 255.0).round().astype(np.uint8)
         if outscale is not None and outscale != float(self.scale):
-            raise NotImplementedError("oracle: cv2.resize INTER_LANCZOS4 outscale not restated (cv2 absent)")
+            from oracle import cv2_ref                         # cv2.resize(..., INTER_LANCZOS4), restated: parity unpinned
+            o3 = output[:, :, None] if output.ndim == 2 else output
+            r = cv2_ref.resize_lanczos4(np.ascontiguousarray(o3), int(h_input * outscale), int(w_input * outscale))
+            output = r[:, :, 0] if output.ndim == 2 else r
         return output, img_mode

@@ -168,3 +168,37 @@ def test_checkpoint_provenance_md5(tmp_path, monkeypatch):
     monkeypatch.setitem(R.KNOWN_CHECKPOINTS, digest, "stand-in for the published file")
     assert R.checkpoint_provenance(str(p))[0] == "verified"
     assert "5db904e3e9f0dbf5c64b7ae665527e62" in R.KNOWN_CHECKPOINTS and "94df4e7c584b55e2e9a5d2b8f161860e" in R.KNOWN_CHECKPOINTS
+
+
+@pytest.mark.parametrize("kind", ["bgr", "gray", "bgra", "u16"])
+@pytest.mark.parametrize("outscale", [1.5, 3.0, 2.0])
+def test_outscale_resizes_with_lanczos4_like_upstream(kind, outscale, golden_dir):
+    """enhance(img, outscale): upstream resizes the finished image with cv2.resize(INTER_LANCZOS4) when outscale differs from
+    the network scale (realesrgan utils.py; reachable from standalone/direct_esrgan.py:130,148 for any IMREAD_UNCHANGED
+    input).  Product (imgproc.py, torch) against the oracle (cv2_ref.py, numpy loops): parity unpinned vs cv2 itself."""
+    crop = np.load(os.path.join(golden_dir, "test_jpeg_crop_64x96_bgr.npy"))[:40, :52]
+    img = G.wrapper_input(kind, np.ascontiguousarray(crop))
+    ours, ref = _both(2, dict(tile=0, tile_pad=10, pre_pad=0))
+    a, ma = ours.enhance(img, outscale=outscale)
+    b, mb = ref.enhance(img, outscale=outscale)
+    assert ma == mb and a.dtype == b.dtype
+    assert a.shape[:2] == (int(40 * outscale), int(52 * outscale)) and a.shape == b.shape
+    lsb = 1 if kind == "u16" else 0            # 16-bit: float sums in another order; 8-bit: fixed point, bit for bit
+    assert np.abs(a.astype(np.int64) - b.astype(np.int64)).max() <= lsb
+    if outscale == 2.0:                         # equal to the network scale: no resize at all
+        assert np.array_equal(a, ours.enhance(img)[0])
+
+
+def test_alpha_upsampler_other_than_realesrgan_is_a_linear_resize(golden_dir):
+    """alpha_upsampler != 'realesrgan': upstream's cv2.resize(alpha, (w * scale, h * scale), INTER_LINEAR) instead of a second
+    network evaluation."""
+    crop = np.load(os.path.join(golden_dir, "test_jpeg_crop_64x96_bgr.npy"))[:40, :52]
+    img = G.wrapper_input("bgra", np.ascontiguousarray(crop))
+    ours, ref = _both(2, dict(tile=0, tile_pad=10, pre_pad=0))
+    a, ma = ours.enhance(img, alpha_upsampler="bicubic")
+    b, mb = ref.enhance(img, alpha_upsampler="bicubic")
+    assert ma == mb == "RGBA" and a.shape == (80, 104, 4)
+    assert np.array_equal(a[:, :, :3], b[:, :, :3])
+    assert np.abs(a[:, :, 3].astype(int) - b[:, :, 3].astype(int)).max() <= 1      # float blend, then the 8-bit rounding
+    net_alpha, _ = ours.enhance(img)
+    assert not np.array_equal(net_alpha[:, :, 3], a[:, :, 3])                        # and it is not the network's alpha

@@ -11,8 +11,8 @@ sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=2)
 frame = synthetic_frame(2160, 3840, seed=0)
 up = RealESRGANer(scale=2, model_path={"params_ema": sd}, model=RRDBNet(3, 3, scale=2, compute_dtype=(sys.argv[1] if len(sys.argv) > 1 else "bf16")), tile=512, tile_pad=10, pre_pad=0, device="cuda")
 up.pre_process(np.ascontiguousarray(frame[:, :, ::-1].astype(np.float32) / 255.0))
-for streams in (1, 2, 3, 4, 6):
-    for batch in (6, 12, 24):
+for streams in (1, 2, 3):
+    for batch in (1, 2, 3, 4, 8, 24):
         up.tile_streams, up.tile_batch = streams, batch
         for _ in range(2):
             up.tile_process()
