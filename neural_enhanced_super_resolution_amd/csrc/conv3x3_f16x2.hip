@@ -36,6 +36,7 @@
 //   epilogue  : bias / LeakyReLU / residuals in f32 (residuals re-joined hi + lo), split, 16-byte
 //               write-through stores of 8 channels per plane; conv_last writes planar f32 / u8.
 #include <cstdlib>
+#include <type_traits>
 
 #include "nesr_kernels.h"
 
@@ -570,6 +571,9 @@ __device__ __forceinline__ void glds16_s_sc1(const char* sbase, unsigned voff, u
 __device__ __forceinline__ void store16_wt(uint16_t* p, uint4 v) {   // write-through: visible device-wide once vmcnt retires it
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(f32x4, v)) : "memory");
 }
+__device__ __forceinline__ void store16_wt_s(const char* sbase, unsigned voff, uint4 v) {   // the same, wave-uniform base + 32-bit lane offset
+    asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(__builtin_bit_cast(f32x4, v)), "s"(sbase) : "memory");
+}
 
 #ifndef NESR_RDB_PUB_DELAY
 #define NESR_RDB_PUB_DELAY 2   // steps between a layer's epilogue and the publication of its progress word
@@ -599,30 +603,44 @@ __device__ __forceinline__ void wait_vmcnt_le(int k) {
 
 #if NESR_RDB_ABL & 256
 __device__ unsigned long long g_rdb_stamps[2][64][8];     // [role: MFMA wave 1 | DMA wave 0][step][event] of workgroup 77
+__device__ unsigned long long g_rdb_arrive[12][8][2];      // [wave][step - 20][arrival at | release from the step's barrier] of workgroup 77
+#define RARRIVE(w, step, ev) do { if (blockIdx.x == 77 && lane == 0 && (step) >= 20 && (step) < 28) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_rdb_arrive[w][(step) - 20][ev] = t_; } } while (0)
 #define RSTAMP(role, step, ev) do { if (blockIdx.x == 77 && lane == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_rdb_stamps[role][step][ev] = t_; } } while (0)
 #else
 #define RSTAMP(role, step, ev) do { } while (0)
+#define RARRIVE(w, step, ev) do { } while (0)
 #endif
 
-constexpr int RSLOTS = 3;   // ring slots of the fused kernel: the DMA waves run two steps ahead
+constexpr int RSLOTS = 4;   // ring slots of the fused kernel: the DMA waves run three steps ahead, step s + 1 has landed at barrier s
 constexpr int MW = 8;       // MFMA waves of the fused kernel: one tile row each, two per SIMD
-constexpr int DW = 4;       // DMA waves: LDS-DMA, neighbour polling, and the layers' epilogues
-constexpr int STAGE_BYTES = MW * 4096;   // accumulator hand-over MFMA waves -> DMA waves: [wave][pixel half, cout half][lane] 16 B
+constexpr int DW = 4;       // DMA waves: LDS-DMA, neighbour polling, progress words
+#ifndef NESR_RDB_PAR
+#define NESR_RDB_PAR 0   // -1: the two MFMA waves of a SIMD run their epilogue halves at opposite ends of a step; 0 / 1: both at the start / end
+#endif
+#ifndef NESR_RDB_EPI_STEPS
+#define NESR_RDB_EPI_STEPS 1
+#endif
+constexpr int EPI_STEPS = NESR_RDB_EPI_STEPS;   // a finished layer's epilogue rides in the first 1 or 2 steps of the next one
+// The DMA waves fetch RSLOTS - 1 steps ahead: the first x1 chunk of conv2 (its step 4) is requested in conv2's step 1, and
+// that request polls this tile's own progress word among the nine -- which goes out EPI_STEPS steps into the layer.
+static_assert(EPI_STEPS <= 4 - (RSLOTS - 1), "the tile would wait for its own progress word");
 
-// Roles.  MFMA waves (0..7): row w of the 8x32-pixel tile, 32 couts, nothing but LDS fragment reads and MFMAs; at the
-// end of a layer they add the cross-term accumulator into the main one and drop the 16 values per lane into the
-// staging area -- ~100 cycles -- and go on with the next layer, whose first steps are already in LDS.  DMA waves
-// (8..11): one step's LDS-DMAs two steps ahead (3-slot ring), and after a layer boundary the epilogue of the finished
-// layer from the staging area (bias, LeakyReLU / residuals, split, whole-line stores), which therefore runs beside the
-// next layer's MFMAs instead of in front of them; the ring's slack covers the ~1.5 us it takes.
+// Roles.  MFMA waves (0..7): row w of the 8x32-pixel tile, 32 couts: LDS fragment reads, MFMAs, and the epilogue of
+// the PREVIOUS (layer, cout group) -- its sums wait in 16 registers (main + cross / 2^11) and are finished (bias,
+// LeakyReLU / residuals, split, whole-line stores) in the first steps of the next layer, one 16-pixel half per step.
+// The two waves of a SIMD do that at opposite ends of the step (waves 0-3 before their MFMAs, 4-7 after), so that the
+// matrix pipe is fed by the one while the other runs ~100 VALU instructions: measured, VALU work issued from an MFMA
+// wave costs ~2 cycles per instruction of step time, against ~16 from a separate wave that competes for issue slots
+// with two MFMA waves (the round-2 design with the epilogue in the DMA waves: boundaries cost 23 % of the kernel).
+// DMA waves (8..11): one step's LDS-DMAs two steps ahead (3-slot ring), polling of the neighbours' progress words
+// before the first chunk of each x_l, and this tile's own progress word EPI_STEPS steps into the next layer.
 __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a) {
     typedef Geo<4> G;
     constexpr int THREADS = G::THREADS, TH = G::TH;      // THREADS = DMA lanes (256), TH = 8 rows
     constexpr int IN_ITEMS = G::IN_ITEMS, IN_ROUNDS = G::IN_ROUNDS, IN_BYTES = G::IN_BYTES;
     constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
     constexpr int WRING = RSLOTS * IN_BYTES;             // LDS: [input ring][weight ring][staging]
-    constexpr int STAGE = RSLOTS * (IN_BYTES + W_BYTES);
-    constexpr int BIAS = STAGE + STAGE_BYTES;            // 6 x 32 f32: conv1..conv4, conv5 couts 0-31, conv5 couts 32-63
+    constexpr int BIAS = RSLOTS * (IN_BYTES + W_BYTES);  // 6 x 32 f32: conv1..conv4, conv5 couts 0-31, conv5 couts 32-63
     static_assert(TH == MW, "one tile row per MFMA wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -736,157 +754,64 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
                 }
             }
         };
-        const int cbl = (g4 & 1) * 16 + (g4 >> 1) * 8;      // a lane's 8 output channels inside a 32-cout group after the permlane16 exchange
-        const int piece8 = ((g4 & 1) * 2 + (g4 >> 1)) * 8;  // its 16-byte piece of a 64-byte slot after regroup_pairs (2-byte units)
-        bool bad = false;
-        // epilogue of (layer l, cout group cg) from the staging area: conv1..4 -> LeakyReLU into cur's channels
-        // 64 + 32 l; conv5 -> x5 * s1 + x0 (and * s2 + RRDB input) into `out`'s channels 32 cg.  DMA wave d finishes
-        // the rows of MFMA waves 2d and 2d + 1.
-        // The six bias vectors of the block sit in LDS (768 B, filled once below): a global load inside the loop would
-        // make the compiler wait vmcnt(0) around it -- i.e. for the LDS-DMAs issued a moment ago -- at every join of the
-        // loop's control flow (measured: the DMA skeleton went from 0.76 to 1.28 us per step).  conv5's residual loads
-        // stay where they are used, inside the l == 4 branch of the epilogue: two pieces per launch pay their latency.
-#if NESR_RDB_ABL & 256
-        int dbg_step = 0;
-#endif
-        const long long chunk_el = a.chunk_bytes >> 1;
-        auto pix_of = [&](int row, int nh, bool& valid) -> size_t {
-            const int X = x0 + 16 * nh + j16;
-            valid = X < a.w_;
-            return ((size_t)n * a.h + (y0 + row)) * a.w_ + (valid ? X : 0);
-        };
+        // The six bias vectors of the block sit in LDS (768 B, filled once here): a global load inside the MFMA waves'
+        // step loop would cost a vmcnt wait per use.
         if (wave == 0 && lane < 48) {
             const int l = lane >> 3 > 4 ? 4 : lane >> 3, cgq = lane >> 3 > 4 ? 8 + (lane & 7) : (lane & 7);   // lanes 32..47: conv5's 64 biases
             *reinterpret_cast<f32x4*>(smem + BIAS + lane * 16) = *reinterpret_cast<const f32x4*>(a.bias[l] + 4 * cgq);
         }
-        auto unpack_res = [&](f32x4 rx, f32x4 rx1, f32x4& q0, f32x4& q1) {
-            uint4 cx = __builtin_bit_cast(uint4, rx), cx1 = __builtin_bit_cast(uint4, rx1);
-            regroup_pairs(cx, cx1);      // -> own hi, own lo
-            const f16x8 h = __builtin_bit_cast(f16x8, cx), lo = __builtin_bit_cast(f16x8, cx1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                q0[i] = fmaf((float)lo[i], LO_INV, (float)h[i]);
-                q1[i] = fmaf((float)lo[4 + i], LO_INV, (float)h[4 + i]);
-            }
-        };
-        // epilogue of (layer l, cout group cg), row rr of this wave, from the staging area: conv1..4 -> LeakyReLU into
-        // cur's channels 64 + 32 l; conv5 -> x5 * s1 + x0 (and * s2 + RRDB input) into `out`'s channels 32 cg.  DMA wave d
-        // finishes the rows of MFMA waves 2d and 2d + 1.  Operands: prefetch(l, cg, rr) of the step before.
-        auto epilogue = [&](int l, int cg, int rr) {
-            const uint16_t* cur16 = static_cast<const uint16_t*>(a.cur);
-            const uint16_t* res2 = static_cast<const uint16_t*>(a.res2);
-            uint16_t* dst16 = l == 4 ? static_cast<uint16_t*>(a.out) : const_cast<uint16_t*>(cur16);
-            const int row = (MW / DW) * wave + rr;
-            if (y0 + row >= a.h) return;          // wave-uniform
-            const char* bsrc = smem + BIAS + (l * 32 + 32 * cg + cbl) * 4;      // conv5's second group follows its first
-            const f32x4 pbz0 = *reinterpret_cast<const f32x4*>(bsrc), pbz1 = *reinterpret_cast<const f32x4*>(bsrc + 16);
-            // the MFMA lane (j16, g) left couts 16 mt + 4 g + i of its pixel at [nh, mt][lane]: this lane wants the 8
-            // consecutive couts cbl .. cbl + 7 = two such runs, g = (cbl & 15) / 4 and the next one (the LDS does the
-            // exchange that the per-layer kernel makes with v_permlane16_swap)
-            const char* stg = smem + STAGE + row * 4096 + ((cbl >> 4) * 1024) + (j16 + 16 * ((cbl & 15) >> 2)) * 16;
-#pragma unroll
-            for (int nh = 0; nh < 2; ++nh) {
-                f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + nh * 2048);
-                f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + nh * 2048 + 256);
-#if NESR_RDB_ABL & 256
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (wave == 0) RSTAMP(1, dbg_step, 4 + 2 * nh);
-#endif
-                bool valid;
-                const size_t pix = pix_of(row, nh, valid);
-                v0 += pbz0;
-                v1 += pbz1;
-                if (l < 4) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { v0[i] = fmaxf(v0[i], v0[i] * 0.2f); v1[i] = fmaxf(v1[i], v1[i] * 0.2f); }   // LeakyReLU(0.2), same values as the select form
-                } else {
-                    const size_t o = (size_t)(2 * cg) * chunk_el + pix * 32 + piece8;      // x0's couts 32 cg ..
-                    const f32x4 r10 = *reinterpret_cast<const f32x4*>(cur16 + o), r11 = *reinterpret_cast<const f32x4*>(cur16 + o + chunk_el);
-                    f32x4 r20 = r10, r21 = r11;
-                    if (res2) { r20 = *reinterpret_cast<const f32x4*>(res2 + o); r21 = *reinterpret_cast<const f32x4*>(res2 + o + chunk_el); }
-                    f32x4 q0, q1;
-                    unpack_res(r10, r11, q0, q1);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s1), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s1), q1[i]); }
-                    if (res2) {
-                        unpack_res(r20, r21, q0, q1);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s2), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s2), q1[i]); }
-                    }
-                }
-                uint4 cx, cx1;
-                bool bad_here = false;
-                split_regroup(v0, v1, cx, cx1, bad_here);
-                bad |= bad_here && valid;
-#if NESR_RDB_ABL & 256
-                if (wave == 0) RSTAMP(1, dbg_step, 5 + 2 * nh);
-#endif
-                if (!valid) continue;
-                uint16_t* pd = dst16 + (size_t)(l == 4 ? 2 * cg : 4 + 2 * l) * chunk_el + pix * 32 + piece8;
-                if (l < 4 && !(NESR_RDB_ABL & 4)) {
-                    store16_wt(pd, cx);
-                    store16_wt(pd + chunk_el, cx1);
-                } else {
-                    *reinterpret_cast<uint4*>(pd) = cx;
-                    *reinterpret_cast<uint4*>(pd + chunk_el) = cx1;
-                }
-            }
-        };
-
         int fl = 0, fcg = 0, fc = 0;      // the next step to fetch
         dma_step(0, 0, 0, 0);
         advance(fl, fcg, fc);
         dma_step(fl, fcg, fc, 1);
         advance(fl, fcg, fc);
+        dma_step(fl, fcg, fc, 2);
+        advance(fl, fcg, fc);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the zero padding is in LDS before the first barrier
-        int fill = 2;
+        int fill = 3;
         int cl = 0, ccg = 0, cc = 0;      // the current step
-        int pub_level = 0;                // > 0: that layer's stores were issued in the previous step -- publish at this barrier
-        int ep_l = 0, ep_cg = 0, ep_rr = MW / DW;   // the epilogue in progress: one of this wave's rows per step
+        // chunk 0 has landed: the MFMA waves request the launch's first fragments behind this barrier
+        wait_vmcnt_le((NESR_RDB_ABL & 96) ? 0 : 2 * kdma);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         for (int step = 0; step < 52; ++step) {
-            // this step's DMAs have landed (the next step's, issued one step ago, may stay in flight; after an epilogue
-            // everything drains, so that its stores have retired before the progress word goes out)
-#if NESR_RDB_ABL & 256
-            dbg_step = step;
-#endif
+            // this step's DMAs and the next step's have landed -- the MFMA waves read the next step's first fragments
+            // before the next barrier -- (those of step + 2, issued one step ago, may stay in flight)
             if (wave == 0) RSTAMP(1, step, 0);
-            wait_vmcnt_le((pub_level > 0 || step == 51 || (NESR_RDB_ABL & 96)) ? 0 : kdma);
+#if NESR_RDB_ABL & 256
+            if ((step == 0 || step == 51) && wave == 0 && blockIdx.x == 77 && lane == 0) {      // shader clock = d memtime / d memrealtime x 100 MHz
+                const unsigned long long r_ = __builtin_amdgcn_s_memrealtime(), t_ = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                g_rdb_stamps[1][step == 0 ? 62 : 63][0] = r_;
+                g_rdb_stamps[1][step == 0 ? 62 : 63][1] = t_;
+            }
+#endif
+            wait_vmcnt_le((step >= 50 || (NESR_RDB_ABL & 96)) ? 0 : kdma);
             if (wave == 0) RSTAMP(1, step, 1);
+            RARRIVE(MW + wave, step, 0);
             if (!(NESR_RDB_ABL & 512)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            RARRIVE(MW + wave, step, 1);
             if (wave == 0) RSTAMP(1, step, 2);
-            if (pub_level > 0) {
-                if (wave == 0 && lane == 0)
-                    __hip_atomic_store(a.progress + tile, a.epoch + (unsigned)pub_level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pub_level = 0;
-            }
-            if (fl < 5) {      // two steps ahead, into the slot read one step ago
+            // layer cl - 1 of this tile is in memory: its MFMA waves stored it during steps 0 .. EPI_STEPS - 1 of layer cl
+            // and waited for those stores (vmcnt(0)) before this barrier
+            if (cc == EPI_STEPS && ccg == 0 && cl >= 1 && wave == 0 && lane == 0)
+                __hip_atomic_store(a.progress + tile, a.epoch + (unsigned)cl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (fl < 5) {      // three steps ahead, into the slot read one step ago
                 dma_step(fl, fcg, fc, fill);
                 advance(fl, fcg, fc);
                 fill = fill == RSLOTS - 1 ? 0 : fill + 1;
             }
-            // the first step of a (layer, cout group): the previous one's sums are in the staging area.  One row now, the
-            // other in the next step, so that this wave is never much later at a barrier than the MFMA waves
             if (wave == 0) RSTAMP(1, step, 3);
-            if (cc == 0 && step > 0) { ep_l = ccg == 1 ? 4 : cl - 1; ep_cg = 0; ep_rr = 0; }
-            if (ep_rr < MW / DW) {
-                if (!(NESR_RDB_ABL & 16)) { if (ep_rr == 0) epilogue(ep_l, ep_cg, 0); else epilogue(ep_l, ep_cg, 1); }
-                if (++ep_rr == MW / DW && ep_l < 4) pub_level = ep_l + 1;
-            }
             advance(cl, ccg, cc);
         }
-        // the last layer's epilogue: nothing is left to overlap it with
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (!(NESR_RDB_ABL & 16)) {
-            epilogue(4, 1, 0);
-            epilogue(4, 1, 1);
-        }
-        if (bad && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
 
     // ---- MFMA role: operand addresses as in conv3x3_f16x2_kernel, one row per wave
+#ifdef NESR_RDB_YPRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(NESR_RDB_YPRIO);     // the later-dispatched wave of each SIMD loses the issue arbitration by age
+#endif
     const bool active = (y0 + wave) < a.h;
     const int un = g4 >> 1, kh = g4 & 1;
     int b16[5][2], a16[5];
@@ -905,117 +830,261 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
 #if NESR_RDB_ABL & 256
     int mstep = 0;
 #endif
+    // ---- the deferred epilogue
+    const int par = (NESR_RDB_PAR >= 0) ? NESR_RDB_PAR : wave >> 2;                          // which end of a step this wave's epilogue half sits at
+    const int cbl = (g4 & 1) * 16 + (g4 >> 1) * 8;      // a lane's 8 output channels inside a 32-cout group after the permlane16 exchange
+    const int piece8 = ((g4 & 1) * 2 + (g4 >> 1)) * 8;  // its 16-byte piece of a 64-byte slot after regroup_pairs (2-byte units)
+    const bool res2 = a.res2 != nullptr;
+    f32x4 ep[2][2];                                     // [pixel half][cout half]: sums of the finished (layer, cout group)
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) ep[nh][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int ep_l = -1, ep_cg = 0;
+    bool bad = false;
+    auto unpack_res = [&](f32x4 rx, f32x4 rx1, f32x4& q0, f32x4& q1) {
+        uint4 cx = __builtin_bit_cast(uint4, rx), cx1 = __builtin_bit_cast(uint4, rx1);
+        regroup_pairs(cx, cx1);      // -> own hi, own lo
+        const f16x8 h = __builtin_bit_cast(f16x8, cx), lo = __builtin_bit_cast(f16x8, cx1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            q0[i] = fmaf((float)lo[i], LO_INV, (float)h[i]);
+            q1[i] = fmaf((float)lo[4 + i], LO_INV, (float)h[4 + i]);
+        }
+    };
+    // pixel half nh of (layer l, cout group cg): conv1..4 -> LeakyReLU into cur's channels 64 + 32 l; conv5 ->
+    // x5 * s1 + x0 (and * s2 + RRDB input) into `out`'s channels 32 cg.  All 64 lanes (v_permlane16_swap).
+    // Addresses: a wave-uniform row base (SGPRs) plus a 32-bit lane offset -- pixel slot and 16-byte piece -- so that
+    // the epilogue carries two VGPRs of addressing instead of 64-bit pointers.
+    const long long row_bytes = (((long long)n * a.h + (y0 + wave)) * a.w_) * 64;
+    unsigned lane_off[2];
+    bool lane_ok[2];
+#pragma unroll
+    for (int nh = 0; nh < 2; ++nh) {
+        const int X = x0 + 16 * nh + j16;
+        lane_ok[nh] = X < a.w_;
+        lane_off[nh] = (unsigned)(lane_ok[nh] ? X : 0) * 64u + (unsigned)piece8 * 2u;
+    }
+    auto uni = [](const char* p) -> const char* {      // tell the compiler the pointer is wave-uniform
+        const unsigned long long v = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return (const char*)(((unsigned long long)hi << 32) | lo);
+    };
+    // pixel half nh of (layer l, cout group cg): conv1..4 -> LeakyReLU into cur's channels 64 + 32 l; conv5 ->
+    // x5 * s1 + x0 (and * s2 + RRDB input) into `out`'s channels 32 cg.  All 64 lanes (v_permlane16_swap).
+    auto epi_half = [&](int l, int cg, const f32x4& e0, const f32x4& e1, int nh) {
+#if NESR_RDB_ABL & 256
+        if (wave == 1) RSTAMP(0, mstep, 3);
+#endif
+        const bool valid = lane_ok[nh];
+        const unsigned voff = lane_off[nh];
+        const char* bsrc = smem + BIAS + (l * 32 + 32 * cg + cbl) * 4;      // conv5's second group follows its first
+        f32x4 v0, v1;   // couts cbl .. cbl+3, cbl+4 .. cbl+7
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const auto sw_ = __builtin_amdgcn_permlane16_swap(__float_as_uint(e0[i]), __float_as_uint(e1[i]), false, false);
+            v0[i] = __uint_as_float(sw_[0]);
+            v1[i] = __uint_as_float(sw_[1]);
+        }
+        v0 += *reinterpret_cast<const f32x4*>(bsrc);
+        v1 += *reinterpret_cast<const f32x4*>(bsrc + 16);
+        const int dchunk = l == 4 ? 2 * cg : 4 + 2 * l;
+        if (l < 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v0[i] = fmaxf(v0[i], v0[i] * 0.2f); v1[i] = fmaxf(v1[i], v1[i] * 0.2f); }   // LeakyReLU(0.2), same values as the select form
+        } else {
+            const char* r1 = uni(static_cast<const char*>(a.cur) + (long long)(2 * cg) * a.chunk_bytes + row_bytes);      // x0's couts 32 cg ..
+            const f32x4 r10 = *reinterpret_cast<const f32x4*>(r1 + voff), r11 = *reinterpret_cast<const f32x4*>(r1 + a.chunk_bytes + voff);
+            f32x4 r20 = r10, r21 = r11;
+            if (res2) {
+                const char* r2 = uni(static_cast<const char*>(a.res2) + (long long)(2 * cg) * a.chunk_bytes + row_bytes);
+                r20 = *reinterpret_cast<const f32x4*>(r2 + voff);
+                r21 = *reinterpret_cast<const f32x4*>(r2 + a.chunk_bytes + voff);
+            }
+            f32x4 q0, q1;
+            unpack_res(r10, r11, q0, q1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s1), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s1), q1[i]); }
+            if (res2) {
+                unpack_res(r20, r21, q0, q1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v0[i] = __fadd_rn(__fmul_rn(v0[i], a.s2), q0[i]); v1[i] = __fadd_rn(__fmul_rn(v1[i], a.s2), q1[i]); }
+            }
+        }
+#if NESR_RDB_ABL & 256
+        asm volatile("" :: "v"(v0), "v"(v1));
+        if (wave == 1) RSTAMP(0, mstep, 4);
+#endif
+        uint4 cx, cx1;
+        bool bad_here = false;
+        split_regroup(v0, v1, cx, cx1, bad_here);
+        bad |= bad_here && valid;
+#if NESR_RDB_ABL & 256
+        asm volatile("" :: "v"(__builtin_bit_cast(f32x4, cx)), "v"(__builtin_bit_cast(f32x4, cx1)));
+        if (wave == 1) RSTAMP(0, mstep, 5);
+#endif
+        if (valid) {
+            const char* d0 = uni(static_cast<const char*>(l == 4 ? a.out : a.cur) + (long long)dchunk * a.chunk_bytes + row_bytes);
+            if (l < 4 && !(NESR_RDB_ABL & 4)) {
+                store16_wt_s(d0, voff, cx);
+                store16_wt_s(d0 + a.chunk_bytes, voff, cx1);
+            } else {
+                *reinterpret_cast<uint4*>(const_cast<char*>(d0) + voff) = cx;
+                *reinterpret_cast<uint4*>(const_cast<char*>(d0) + a.chunk_bytes + voff) = cx1;
+            }
+        }
+#if NESR_RDB_ABL & 256
+        if (wave == 1) RSTAMP(0, mstep, 6);
+#endif
+    };
+    // the part of the pending epilogue that belongs to step c of the running layer
+    auto epi_part = [&](int c) {
+        if (NESR_RDB_ABL & 16) return;
+        if (EPI_STEPS == 1) {
+            epi_half(ep_l, ep_cg, ep[0][0], ep[0][1], 0);
+            epi_half(ep_l, ep_cg, ep[1][0], ep[1][1], 1);
+        } else if (c == 0) {
+            epi_half(ep_l, ep_cg, ep[0][0], ep[0][1], 0);
+        } else {
+            epi_half(ep_l, ep_cg, ep[1][0], ep[1][1], 1);
+        }
+    };
+    f32x4 acc16[2][2][2];       // [pixel half][cout half][main | cross]
+    f32x4 Af[2][2][2];          // [buffer][cout half][variant]
+    f32x4 Bf[2][2][2];          // [buffer][pixel half][variant]
+    // fragments of tap-step s_ of the step in ring slot `sl` -> buffer `buf`
+    auto load_step = [&](int sl, int s_, int buf) {
+        const char* st = smem + sl * IN_BYTES;
+        const char* swb = smem + WRING + sl * W_BYTES;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            if ((NESR_RDB_ABL & 1024) && s_ > 0) {         // timing only: weight fragments read once per step
+                Af[buf][mt][0] = Af[buf ^ 1][mt][0];
+                Af[buf][mt][1] = Af[buf ^ 1][mt][1];
+            } else if (s_ < 4) {
+                Af[buf][mt][0] = *reinterpret_cast<const f32x4*>(swb + a16[s_] + mt * 256);
+                Af[buf][mt][1] = *reinterpret_cast<const f32x4*>(swb + a16[s_] + mt * 256 + 1024);
+            } else {
+                f32x4 hi = *reinterpret_cast<const f32x4*>(swb + a16[4] + mt * 256);
+                Af[buf][mt][1] = *reinterpret_cast<const f32x4*>(swb + a16[4] + mt * 256 + un * 1024);
+                if (un) hi = f32x4{0.f, 0.f, 0.f, 0.f};
+                Af[buf][mt][0] = hi;
+            }
+        }
+#pragma unroll
+        for (int nh = 0; nh < 2; ++nh) {
+            if ((NESR_RDB_ABL & 2048) && s_ > 0) {         // timing only: activation fragments read once per step
+                Bf[buf][nh][0] = Bf[buf ^ 1][nh][0];
+                Bf[buf][nh][1] = Bf[buf ^ 1][nh][1];
+                continue;
+            }
+            const int o0 = b16[s_][nh];
+            const int o1 = s_ == 4 ? (b16[4][nh] ^ ((un ^ 1) << 5)) : (b16[s_][nh] ^ 32);
+            Bf[buf][nh][0] = *reinterpret_cast<const f32x4*>(st + o0);
+            Bf[buf][nh][1] = *reinterpret_cast<const f32x4*>(st + o1);
+        }
+    };
+    // One step = 5 tap-steps of the chunk in ring slot `slot`; P = buffer parity of its first tap-step (5 is odd: it
+    // flips every step, and every layer has an even number of steps).  The fragments of tap-step 0 were requested in
+    // the previous step (or just below, for the launch's first step); those of the next step's tap-step 0 are requested
+    // beside this step's last MFMAs -- the next step's chunk landed before this step's barrier -- so that no wave sits
+    // behind an LDS round trip after a barrier.
+    auto step_body = [&](auto Pc, int c, bool last_of_all) {
+        constexpr int P = decltype(Pc)::value;
+        // the x_l stores of this wave have retired before the barrier after which the progress word goes out
+        if (c == EPI_STEPS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if NESR_RDB_ABL & 256
+        if (wave == 1) RSTAMP(0, mstep, 0);
+        RARRIVE(wave, mstep, 0);
+#endif
+        if (!(NESR_RDB_ABL & 512)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#if NESR_RDB_ABL & 256
+        RARRIVE(wave, mstep, 1);
+        if (wave == 1) RSTAMP(0, mstep, 1);
+#endif
+        const bool epi_now = active && ep_l >= 0 && c < EPI_STEPS;
+        const int nslot = slot == RSLOTS - 1 ? 0 : slot + 1;
+        if (active && !(NESR_RDB_ABL & 8)) {
+            if (epi_now && par == 0) {
+                epi_part(c);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < 5; ++s_) {
+                const int buf = (s_ + P) & 1;
+                if (s_ + 1 < 5) load_step(slot, s_ + 1, buf ^ 1);
+                else if (!last_of_all) load_step(nslot, 0, buf ^ 1);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const f16x8 a0 = __builtin_bit_cast(f16x8, Af[buf][mt][0]), a1 = __builtin_bit_cast(f16x8, Af[buf][mt][1]);
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh) {
+                        const f16x8 x0_ = __builtin_bit_cast(f16x8, Bf[buf][nh][0]), x1_ = __builtin_bit_cast(f16x8, Bf[buf][nh][1]);
+                        if (s_ < 4) {
+                            acc16[nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x1_, acc16[nh][mt][1], 0, 0, 0);
+                            acc16[nh][mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x0_, acc16[nh][mt][0], 0, 0, 0);
+                            acc16[nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x0_, acc16[nh][mt][1], 0, 0, 0);
+                        } else {
+                            acc16[nh][mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x0_, acc16[nh][mt][0], 0, 0, 0);
+                            acc16[nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1_, acc16[nh][mt][1], 0, 0, 0);
+                        }
+                    }
+                }
+                // the next tap-step's 8 fragment reads ride between this one's MFMAs
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (epi_now && par == 1) {
+                epi_part(c);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        slot = nslot;
+#if NESR_RDB_ABL & 256
+        if (wave == 1) RSTAMP(0, mstep, 2);
+        ++mstep;
+#endif
+    };
+    // the launch's first fragments: chunk 0 is in LDS once every DMA wave has passed its first wait -- one extra barrier
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (active) load_step(0, 0, 0);
     for (int l = 0; l < 5; ++l) {
         const int nc = l == 4 ? 12 : 4 + 2 * l;
         const int ncg = l == 4 ? 2 : 1;
         for (int cg = 0; cg < ncg; ++cg) {
-            f32x4 acc16[2][2][2];       // [pixel half][cout half][main | cross]
 #pragma unroll
             for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int q = 0; q < 2; ++q) acc16[nh][mt][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int c = 0; c < nc; ++c) {
-                // the staging writes of the previous layer (if any) have completed before the barrier that hands them over
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if NESR_RDB_ABL & 256
-                if (wave == 1) RSTAMP(0, mstep, 0);
-#endif
-                if (!(NESR_RDB_ABL & 512)) __builtin_amdgcn_s_barrier();
-                asm volatile("" ::: "memory");
-#if NESR_RDB_ABL & 256
-                if (wave == 1) RSTAMP(0, mstep, 1);
-#endif
-                if (active && !(NESR_RDB_ABL & 8)) {
-                    const char* st = smem + slot * IN_BYTES;
-                    const char* swb = smem + WRING + slot * W_BYTES;
-                    f32x4 Af[2][2][2];     // [buffer][cout half][variant]
-                    f32x4 Bf[2][2][2];     // [buffer][pixel half][variant]
-                    auto load_step = [&](int s_, int buf) {
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {
-                            if (s_ < 4) {
-                                Af[buf][mt][0] = *reinterpret_cast<const f32x4*>(swb + a16[s_] + mt * 256);
-                                Af[buf][mt][1] = *reinterpret_cast<const f32x4*>(swb + a16[s_] + mt * 256 + 1024);
-                            } else {
-                                f32x4 hi = *reinterpret_cast<const f32x4*>(swb + a16[4] + mt * 256);
-                                Af[buf][mt][1] = *reinterpret_cast<const f32x4*>(swb + a16[4] + mt * 256 + un * 1024);
-                                if (un) hi = f32x4{0.f, 0.f, 0.f, 0.f};
-                                Af[buf][mt][0] = hi;
-                            }
-                        }
-#pragma unroll
-                        for (int nh = 0; nh < 2; ++nh) {
-                            const int o0 = b16[s_][nh];
-                            const int o1 = s_ == 4 ? (b16[4][nh] ^ ((un ^ 1) << 5)) : (b16[s_][nh] ^ 32);
-                            Bf[buf][nh][0] = *reinterpret_cast<const f32x4*>(st + o0);
-                            Bf[buf][nh][1] = *reinterpret_cast<const f32x4*>(st + o1);
-                        }
-                    };
-                    load_step(0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int s_ = 0; s_ < 5; ++s_) {
-                        const int buf = s_ & 1;
-                        if (s_ + 1 < 5) load_step(s_ + 1, buf ^ 1);
-                        if (NESR_RDB_ABL & 128) {      // LDS reads kept alive, no MFMA
-#pragma unroll
-                            for (int mt = 0; mt < 2; ++mt) { asm volatile("" ::"v"(Af[buf][mt][0]), "v"(Af[buf][mt][1])); }
-#pragma unroll
-                            for (int nh = 0; nh < 2; ++nh) { asm volatile("" ::"v"(Bf[buf][nh][0]), "v"(Bf[buf][nh][1])); }
-                            continue;
-                        }
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {
-                            const f16x8 a0 = __builtin_bit_cast(f16x8, Af[buf][mt][0]), a1 = __builtin_bit_cast(f16x8, Af[buf][mt][1]);
-#pragma unroll
-                            for (int nh = 0; nh < 2; ++nh) {
-                                const f16x8 x0_ = __builtin_bit_cast(f16x8, Bf[buf][nh][0]), x1_ = __builtin_bit_cast(f16x8, Bf[buf][nh][1]);
-                                if (s_ < 4) {
-                                    acc16[nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x1_, acc16[nh][mt][1], 0, 0, 0);
-                                    acc16[nh][mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x0_, acc16[nh][mt][0], 0, 0, 0);
-                                    acc16[nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x0_, acc16[nh][mt][1], 0, 0, 0);
-                                } else {
-                                    acc16[nh][mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, x0_, acc16[nh][mt][0], 0, 0, 0);
-                                    acc16[nh][mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, x1_, acc16[nh][mt][1], 0, 0, 0);
-                                }
-                            }
-                        }
-                        // the next step's 8 fragment reads ride between this step's MFMAs
-                        if (s_ + 1 < 5) {
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-                            }
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                slot = slot == RSLOTS - 1 ? 0 : slot + 1;
-#if NESR_RDB_ABL & 256
-                if (wave == 1) RSTAMP(0, mstep, 2);
-                ++mstep;
-#endif
+            for (int c = 0; c < nc; c += 2) {
+                step_body(std::integral_constant<int, 0>{}, c, false);
+                step_body(std::integral_constant<int, 1>{}, c + 1, l == 4 && cg == 1 && c + 2 == nc);
             }
-            // the layer's sums -> staging area (main + cross / 2^11): [row][pixel half, cout half][lane]
-            if (active) {
-                char* stg = smem + STAGE + wave * 4096 + lane * 16;
+            // the layer's sums (main + cross / 2^11) wait for the next layer's first steps
 #pragma unroll
-                for (int nh = 0; nh < 2; ++nh)
+            for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        f32x4 e;
+                for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) e[i] = fmaf(acc16[nh][mt][1][i], LO_INV, acc16[nh][mt][0][i]);
-                        *reinterpret_cast<f32x4*>(stg + (nh * 2 + mt) * 1024) = e;
-                    }
-            }
+                    for (int i = 0; i < 4; ++i) ep[nh][mt][i] = fmaf(acc16[nh][mt][1][i], LO_INV, acc16[nh][mt][0][i]);
+            ep_l = l;
+            ep_cg = cg;
         }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    // the last cout group of conv5: nothing is left to overlap it with
+    if (active && !(NESR_RDB_ABL & 16)) {
+        epi_half(4, 1, ep[0][0], ep[0][1], 0);
+        epi_half(4, 1, ep[1][0], ep[1][1], 1);
+    }
+    if (bad && a.status) __hip_atomic_store(a.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int DMAW>
@@ -1046,6 +1115,9 @@ inline float h2f(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
 #if NESR_RDB_ABL & 256
 extern "C" int nesr_debug_rdb_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rdb_stamps), sizeof(unsigned long long) * 2 * 64 * 8);
+}
+extern "C" int nesr_debug_rdb_arrive(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rdb_arrive), sizeof(unsigned long long) * 12 * 8 * 2);
 }
 #endif
 #if NESR_ABL & 64
@@ -1081,7 +1153,7 @@ int rdb_f16x2_tiles(int n, int h, int w) { return ((w + TW - 1) / TW) * ((h + 7)
 
 hipError_t launch_rdb_f16x2(const RdbLaunch& r, hipStream_t s) {
     typedef Geo<4> G;
-    constexpr size_t shm = (size_t)RSLOTS * (G::IN_BYTES + (size_t)W_BYTES) + STAGE_BYTES + 768;
+    constexpr size_t shm = (size_t)RSLOTS * (G::IN_BYTES + (size_t)W_BYTES) + 768;
     static unsigned long long attr_done = 0;
     {
         const hipError_t e = ensure_dynamic_lds(reinterpret_cast<const void*>(&rdb_f16x2_kernel), shm, attr_done);

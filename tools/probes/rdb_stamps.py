@@ -28,7 +28,18 @@ for s in range(52):
     nm = S[0][s + 1][0] if s < 51 else m[2]
     nd = S[1][s + 1][0] if s < 51 else d[3]
     ep = ""
-    if d[4] > d[3]:
-        ep = f"  epilogue: lds {d[4]-d[3]} math {d[5]-d[4]} store+lds {d[6]-d[5]} math {d[7]-d[6]} store {nd-d[7]}"
+    if m[3] > m[1] and m[6] > m[3]:
+        ep = f"  epilogue in the MFMA wave: start +{m[3]-m[1]} exchange/bias/act {m[4]-m[3]} split/regroup {m[5]-m[4]} stores {m[6]-m[5]}"
     print(f"{s:3d} | {m[0]-t0:8d} {m[1]-m[0]:6d} {m[2]-m[1]:6d} | {d[0]-t0:8d} ({d[1]-d[0]:5d}) {d[2]-d[1]:6d} {d[3]-d[2]:6d} {nd-d[3]:6d} | {nm-m[0]:6d}{ep}")
 print("total cycles", S[0][51][2] - t0)
+dr, dt = S[1][63][0] - S[1][62][0], S[1][63][1] - S[1][62][1]
+print(f"steps 0..51: {dt} shader cycles in {dr} ticks of the 100 MHz clock = {dr / 100:.2f} us: shader clock {dt / dr * 100:.0f} MHz")
+
+arr = (ctypes.c_ulonglong * (12 * 8 * 2))()
+lib.nesr_debug_rdb_arrive.argtypes = [ctypes.c_void_p]
+if lib.nesr_debug_rdb_arrive(arr) == 0:
+    print("barrier arrival of every wave (MFMA 0-7, DMA 8-11) relative to the release of that barrier, steps 20..27")
+    for st in range(8):
+        rel = max(arr[(w * 8 + st) * 2 + 0] for w in range(12))
+        print(20 + st, " ".join(f"{int(arr[(w * 8 + st) * 2 + 0]) - int(rel):6d}" for w in range(12)),
+              "| release seen", " ".join(f"{int(arr[(w * 8 + st) * 2 + 1]) - int(rel):5d}" for w in range(12)))
