@@ -603,6 +603,7 @@ __device__ __forceinline__ void wait_vmcnt_le(int k) {
 
 #if NESR_RDB_ABL & 256
 __device__ unsigned long long g_rdb_stamps[2][64][8];     // [role: MFMA wave 1 | DMA wave 0][step][event] of workgroup 77
+__device__ unsigned long long g_rdb_taps[2][8][8];         // [MFMA wave 1 | 5 (one SIMD)][step - 20][start of tap-step 0..4, end] of workgroup 77
 __device__ unsigned long long g_rdb_arrive[12][8][2];      // [wave][step - 20][arrival at | release from the step's barrier] of workgroup 77
 #define RARRIVE(w, step, ev) do { if (blockIdx.x == 77 && lane == 0 && (step) >= 20 && (step) < 28) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_rdb_arrive[w][(step) - 20][ev] = t_; } } while (0)
 #define RSTAMP(role, step, ev) do { if (blockIdx.x == 77 && lane == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_rdb_stamps[role][step][ev] = t_; } } while (0)
@@ -735,7 +736,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
                     const unsigned v = watch ? __hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
                     if (__builtin_amdgcn_ballot_w64((int)(v - target) < 0) == 0ull) break;
                     if (it > (1u << 22)) {     // ~1 s: a neighbour never arrived (workgroups not co-resident?)
-                        if (lane == 0) __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0) __hip_atomic_store(a.abort_flag, 1u | ((unsigned)c << 8) | ((unsigned)tile << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         break;
                     }
                     __builtin_amdgcn_s_sleep(4);
@@ -830,6 +831,19 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
 #if NESR_RDB_ABL & 256
     int mstep = 0;
 #endif
+    // Fragment addresses live in registers as absolute LDS addresses of the slot they are read from next; each is used
+    // once per step and moved on to the next slot right away (one v_add per register and step; the pixel half and the
+    // weight variants are immediate offsets) instead of slot base + offset per read (one v_add per ds_read).
+    typedef const __attribute__((address_space(3))) f32x4* lds_f32x4;
+    const unsigned lds0 = (unsigned)(size_t)(lds_char*)(smem);
+    unsigned bcur[5][2], acur[5], acur4b;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+        bcur[t][0] = lds0 + (unsigned)b16[t][0];
+        bcur[t][1] = lds0 + (unsigned)(t == 4 ? (b16[4][0] ^ ((un ^ 1) << 5)) : (b16[t][0] ^ 32));
+        acur[t] = lds0 + (unsigned)(WRING + a16[t]);
+    }
+    acur4b = acur[4] + (unsigned)un * 1024u;
     // ---- the deferred epilogue
     const int par = (NESR_RDB_PAR >= 0) ? NESR_RDB_PAR : wave >> 2;                          // which end of a step this wave's epilogue half sits at
     const int cbl = (g4 & 1) * 16 + (g4 >> 1) * 8;      // a lane's 8 output channels inside a 32-cout group after the permlane16 exchange
@@ -952,37 +966,33 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
     f32x4 acc16[2][2][2];       // [pixel half][cout half][main | cross]
     f32x4 Af[2][2][2];          // [buffer][cout half][variant]
     f32x4 Bf[2][2][2];          // [buffer][pixel half][variant]
-    // fragments of tap-step s_ of the step in ring slot `sl` -> buffer `buf`
+    // fragments of tap-step s_ of the step in ring slot `sl` -> buffer `buf`; the addresses move on to slot sl + 1
+    // (the second pixel half is 16 pixels = 1024 bytes on: the slot swizzle looks at bit 2 of the column only)
     auto load_step = [&](int sl, int s_, int buf) {
-        const char* st = smem + sl * IN_BYTES;
-        const char* swb = smem + WRING + sl * W_BYTES;
+        const bool wrap = sl == RSLOTS - 1;
+        const unsigned dB = wrap ? (unsigned)(-(RSLOTS - 1) * IN_BYTES) : (unsigned)IN_BYTES;
+        const unsigned dA = wrap ? (unsigned)(-(RSLOTS - 1) * W_BYTES) : (unsigned)W_BYTES;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            if ((NESR_RDB_ABL & 1024) && s_ > 0) {         // timing only: weight fragments read once per step
-                Af[buf][mt][0] = Af[buf ^ 1][mt][0];
-                Af[buf][mt][1] = Af[buf ^ 1][mt][1];
-            } else if (s_ < 4) {
-                Af[buf][mt][0] = *reinterpret_cast<const f32x4*>(swb + a16[s_] + mt * 256);
-                Af[buf][mt][1] = *reinterpret_cast<const f32x4*>(swb + a16[s_] + mt * 256 + 1024);
+            if (s_ < 4) {
+                Af[buf][mt][0] = *((lds_f32x4)(size_t)(acur[s_] + mt * 256));
+                Af[buf][mt][1] = *((lds_f32x4)(size_t)(acur[s_] + mt * 256 + 1024));
             } else {
-                f32x4 hi = *reinterpret_cast<const f32x4*>(swb + a16[4] + mt * 256);
-                Af[buf][mt][1] = *reinterpret_cast<const f32x4*>(swb + a16[4] + mt * 256 + un * 1024);
+                f32x4 hi = *((lds_f32x4)(size_t)(acur[4] + mt * 256));
+                Af[buf][mt][1] = *((lds_f32x4)(size_t)(acur4b + mt * 256));
                 if (un) hi = f32x4{0.f, 0.f, 0.f, 0.f};
                 Af[buf][mt][0] = hi;
             }
         }
 #pragma unroll
         for (int nh = 0; nh < 2; ++nh) {
-            if ((NESR_RDB_ABL & 2048) && s_ > 0) {         // timing only: activation fragments read once per step
-                Bf[buf][nh][0] = Bf[buf ^ 1][nh][0];
-                Bf[buf][nh][1] = Bf[buf ^ 1][nh][1];
-                continue;
-            }
-            const int o0 = b16[s_][nh];
-            const int o1 = s_ == 4 ? (b16[4][nh] ^ ((un ^ 1) << 5)) : (b16[s_][nh] ^ 32);
-            Bf[buf][nh][0] = *reinterpret_cast<const f32x4*>(st + o0);
-            Bf[buf][nh][1] = *reinterpret_cast<const f32x4*>(st + o1);
+            Bf[buf][nh][0] = *((lds_f32x4)(size_t)(bcur[s_][0] + nh * 1024));
+            Bf[buf][nh][1] = *((lds_f32x4)(size_t)(bcur[s_][1] + nh * 1024));
         }
+        acur[s_] += dA;
+        if (s_ == 4) acur4b += dA;
+        bcur[s_][0] += dB;
+        bcur[s_][1] += dB;
     };
     // One step = 5 tap-steps of the chunk in ring slot `slot`; P = buffer parity of its first tap-step (5 is odd: it
     // flips every step, and every layer has an even number of steps).  The fragments of tap-step 0 were requested in
@@ -1010,9 +1020,16 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
                 epi_part(c);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#if NESR_RDB_ABL & 256
+            unsigned long long tt[6];
+#endif
 #pragma unroll
             for (int s_ = 0; s_ < 5; ++s_) {
                 const int buf = (s_ + P) & 1;
+#if NESR_RDB_ABL & 256
+                tt[s_] = __builtin_amdgcn_s_memtime();      // no wait here: read at the end of the step
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 if (s_ + 1 < 5) load_step(slot, s_ + 1, buf ^ 1);
                 else if (!last_of_all) load_step(nslot, 0, buf ^ 1);
 #pragma unroll
@@ -1043,6 +1060,13 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
                 epi_part(c);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#if NESR_RDB_ABL & 256
+            tt[5] = __builtin_amdgcn_s_memtime();
+            if (blockIdx.x == 77 && (wave == 1 || wave == 5) && lane == 0 && mstep >= 20 && mstep < 28) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) g_rdb_taps[wave == 5][mstep - 20][i] = tt[i];
+            }
+#endif
         }
         slot = nslot;
 #if NESR_RDB_ABL & 256
@@ -1115,6 +1139,9 @@ inline float h2f(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
 #if NESR_RDB_ABL & 256
 extern "C" int nesr_debug_rdb_stamps(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rdb_stamps), sizeof(unsigned long long) * 2 * 64 * 8);
+}
+extern "C" int nesr_debug_rdb_taps(unsigned long long* out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rdb_taps), sizeof(unsigned long long) * 2 * 8 * 8);
 }
 extern "C" int nesr_debug_rdb_arrive(unsigned long long* out) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rdb_arrive), sizeof(unsigned long long) * 12 * 8 * 2);

@@ -765,12 +765,14 @@ int nesr_check_range(nesr_ctx* c, void* stream) {
     HIP_TRY(hipMemcpyAsync(c->h_status, c->d_status, 8, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     if (c->h_status[1]) {
+        const unsigned code = c->h_status[1];      // 1 | chunk whose producer was waited for << 8 | tile << 16
         HIP_TRY(hipMemsetAsync(c->d_status, 0, 8, s));
         HIP_TRY(hipStreamSynchronize(s));
         c->h_status[0] = c->h_status[1] = 0;
-        return fail(NESR_ERR_HIP, "the fused dense-block kernel gave up waiting for a neighbouring tile (its workgroups were not all "
-                                  "resident: another persistent kernel shares the device?); the output of that forward is invalid. "
-                                  "NESR_RDB_FUSE=0 selects per-layer launches");
+        return fail(NESR_ERR_HIP, "the fused dense-block kernel gave up waiting for a neighbouring tile's progress word (tile " +
+                                  std::to_string(code >> 16) + ", input chunk " + std::to_string((code >> 8) & 255u) +
+                                  ": its workgroups were not all resident -- another persistent kernel shares the device?); the "
+                                  "output of that forward is invalid. NESR_RDB_FUSE=0 selects per-layer launches");
     }
     if (*c->h_status) {
         HIP_TRY(hipMemsetAsync(c->d_status, 0, 4, s));   // reported once; the next forward starts clean

@@ -43,3 +43,13 @@ if lib.nesr_debug_rdb_arrive(arr) == 0:
         rel = max(arr[(w * 8 + st) * 2 + 0] for w in range(12))
         print(20 + st, " ".join(f"{int(arr[(w * 8 + st) * 2 + 0]) - int(rel):6d}" for w in range(12)),
               "| release seen", " ".join(f"{int(arr[(w * 8 + st) * 2 + 1]) - int(rel):5d}" for w in range(12)))
+
+tp = (ctypes.c_ulonglong * (2 * 8 * 8))()
+if hasattr(lib, "nesr_debug_rdb_taps"):
+    lib.nesr_debug_rdb_taps.argtypes = [ctypes.c_void_p]
+    if lib.nesr_debug_rdb_taps(tp) == 0:
+        print("tap-steps of MFMA waves 1 and 5 (the two of one SIMD), steps 20..27: start of tap-step 0..4 and end, relative to wave 1's tap-step 0")
+        for st in range(8):
+            b = int(tp[(0 * 8 + st) * 8 + 0])
+            for w in range(2):
+                print(20 + st, "wave", 1 + 4 * w, " ".join(f"{int(tp[(w * 8 + st) * 8 + i]) - b:6d}" for i in range(6)))
