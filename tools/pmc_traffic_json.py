@@ -3,8 +3,8 @@
 
     tools/pmc_traffic_json.py <key> <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> [--launches-per-frame N]
 
-HBM bytes per conv launch = (sum FETCH_SIZE x 2 + sum WRITE_SIZE) x 1024 / conv dispatches, over every conv3x3 kernel of the
-run: FETCH_SIZE / WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads
+HBM bytes per launch = (sum FETCH_SIZE x 2 + sum WRITE_SIZE) x 1024 / dispatches, over the dominant kernel of the run (the
+fused dense-block kernel, or every conv3x3 kernel when the run used per-layer launches): FETCH_SIZE / WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads
 (MI355X_MICROARCH.md, HBM section).  The file is stamped with the hash of the kernel sources (bench.csrc_sha16) so that
 bench.py reports `traffic: null` once the kernels have changed."""
 import csv
@@ -19,13 +19,14 @@ from bench import csrc_sha16  # noqa: E402
 
 
 def total(d, counter):
-    n, s = 0, 0.0
+    """(dispatches, sum) over the dominant kernel of the run: the fused dense-block kernel when the run used it (its 69
+    launches per frame are the 345 dense-block convs -- the kernel bench.py's `roofline` is about), else every conv3x3 kernel."""
+    rows = []
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and "conv3x3" in r["Kernel_Name"]:
-                n += 1
-                s += float(r["Counter_Value"])
-    return n, s
+        rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    fused = [r for r in rows if "rdb_f16x2" in r["Kernel_Name"]]
+    sel = fused if fused else [r for r in rows if "conv3x3" in r["Kernel_Name"]]
+    return len(sel), sum(float(r["Counter_Value"]) for r in sel)
 
 
 def main():
@@ -44,7 +45,7 @@ def main():
         d = {"csrc_sha16": sha}
     d[key] = per_launch
     json.dump(d, open(path, "w"))
-    print(f"{key}: {per_launch} bytes per conv launch over {nf} dispatches (fetch x2 {2 * fetch * 1024 / nf:.0f} + write {write * 1024 / nf:.0f}); csrc {sha}")
+    print(f"{key}: {per_launch} bytes per launch over {nf} dispatches (fetch x2 {2 * fetch * 1024 / nf:.0f} + write {write * 1024 / nf:.0f}); csrc {sha}")
 
 
 if __name__ == "__main__":
