@@ -575,9 +575,6 @@ __device__ __forceinline__ void store16_wt_s(const char* sbase, unsigned voff, u
     asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(__builtin_bit_cast(f32x4, v)), "s"(sbase) : "memory");
 }
 
-#ifndef NESR_RDB_PUB_DELAY
-#define NESR_RDB_PUB_DELAY 2   // steps between a layer's epilogue and the publication of its progress word
-#endif
 #ifndef NESR_RDB_ABL
 #define NESR_RDB_ABL 0   // timing ablations (WRONG results): 1 no neighbour polling, 2 plain activation loads, 4 plain x1..x4 stores, 8 no MFMA, 16 no epilogue
 #endif
@@ -628,19 +625,19 @@ static_assert(EPI_STEPS <= 4 - (RSLOTS - 1), "the tile would wait for its own pr
 
 // Roles.  MFMA waves (0..7): row w of the 8x32-pixel tile, 32 couts: LDS fragment reads, MFMAs, and the epilogue of
 // the PREVIOUS (layer, cout group) -- its sums wait in 16 registers (main + cross / 2^11) and are finished (bias,
-// LeakyReLU / residuals, split, whole-line stores) in the first steps of the next layer, one 16-pixel half per step.
-// The two waves of a SIMD do that at opposite ends of the step (waves 0-3 before their MFMAs, 4-7 after), so that the
-// matrix pipe is fed by the one while the other runs ~100 VALU instructions: measured, VALU work issued from an MFMA
-// wave costs ~2 cycles per instruction of step time, against ~16 from a separate wave that competes for issue slots
-// with two MFMA waves (the round-2 design with the epilogue in the DMA waves: boundaries cost 23 % of the kernel).
-// DMA waves (8..11): one step's LDS-DMAs two steps ahead (3-slot ring), polling of the neighbours' progress words
+// LeakyReLU / residuals, split, whole-line stores) at the start of the next layer's first step, by both waves of a SIMD
+// at the same point (NESR_RDB_PAR 0).  Measured alternatives: the epilogue in the DMA waves, or in
+// four waves of its own -- a VALU instruction of a wave that shares its SIMD with two MFMA waves gets one issue slot
+// per MFMA, ~16 cycles each: layer boundaries cost 23 % of the kernel; staggered between the two MFMA waves of a SIMD
+// (one before, one after its MFMAs) -- a VALU block beside the partner's MFMA stream crawls just the same.
+// DMA waves (8..11): one step's LDS-DMAs three steps ahead (4-slot ring), polling of the neighbours' progress words
 // before the first chunk of each x_l, and this tile's own progress word EPI_STEPS steps into the next layer.
 __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a) {
     typedef Geo<4> G;
     constexpr int THREADS = G::THREADS, TH = G::TH;      // THREADS = DMA lanes (256), TH = 8 rows
     constexpr int IN_ITEMS = G::IN_ITEMS, IN_ROUNDS = G::IN_ROUNDS, IN_BYTES = G::IN_BYTES;
     constexpr int W_ROUNDS = (W_ITEMS + THREADS - 1) / THREADS;
-    constexpr int WRING = RSLOTS * IN_BYTES;             // LDS: [input ring][weight ring][staging]
+    constexpr int WRING = RSLOTS * IN_BYTES;             // LDS: [input ring][weight ring][bias table]
     constexpr int BIAS = RSLOTS * (IN_BYTES + W_BYTES);  // 6 x 32 f32: conv1..conv4, conv5 couts 0-31, conv5 couts 32-63
     static_assert(TH == MW, "one tile row per MFMA wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -672,8 +669,8 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
         if (++c == nc) { c = 0; if (++cg == ncg) { cg = 0; ++l; } }
     };
 
-    // The two roles run separate loops over the same 52 steps (one s_barrier per step, one more before the last
-    // epilogue): their register sets never coexist.
+    // The two roles run separate loops over the same 52 steps (one s_barrier per step, one more before the first):
+    // their register sets never coexist.
     if (is_dma) {
 #ifndef NESR_RDB_NOPRIO
         __builtin_amdgcn_s_setprio(3);     // everything waits for what these four waves issue: they win the issue arbitration
