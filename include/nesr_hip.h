@@ -100,6 +100,23 @@ int nesr_forward(nesr_ctx* ctx, const void* x_dev, int N, int C, int H, int W, v
 int nesr_forward_u8(nesr_ctx* ctx, const uint8_t* in_hwc_dev, int H, int W, uint8_t* out_hwc_dev,
                     int flip_rgb, int round_mode, void* stream);
 
+/*
+ * Forward pass on N images of DIFFERENT sizes in one batch: the tiles of one frame as realesrgan's tile_process cuts them
+ * (`for y in range(tiles_y): for x in range(tiles_x): ... self.model(input_tile)`, called from
+ * standalone/direct_esrgan.py:148 with tile=512, tile_pad=10 -- interior tiles 532 x 532, edge and corner tiles smaller).
+ * Image i lies in the top-left hw[2i] x hw[2i+1] pixels of slot i of x_dev ([N, C, H, W] f32; the rest of a slot is
+ * ignored) and its output in the top-left of slot i of y_dev ([N, num_out_ch, 4H/u, 4W/u]; the rest is not written).
+ * Each image is evaluated as an image of its own -- its borders are the zero padding of every conv -- with the values
+ * nesr_forward gives it alone (see nesr_set_size_independent).  hw: host array of N (height, width) pairs, multiples of
+ * the unshuffle factor, 1 <= N <= 64.  compute dtype bf16 only (NESR_ERR_ARG otherwise: the f32 forms batch equal shapes).
+ */
+int nesr_forward_ragged(nesr_ctx* ctx, const void* x_dev, int N, int C, int H, int W, const int* hw, void* y_dev, void* stream);
+
+/* Choose kernels by arithmetic only, never by image size (bf16: the large-tile kernel also for small images), so that an
+ * image's values are the same bits alone, in an equal-shape batch and in a ragged batch.  RealESRGANer sets it for a
+ * tiling wrapper.  Slower for single small frames; off by default. */
+int nesr_set_size_independent(nesr_ctx* ctx, int on);
+
 /* Device bytes of activation workspace forward() needs for a batch of N frames of H x W input. */
 size_t nesr_workspace_bytes(const nesr_ctx* ctx, int N, int H, int W);
 

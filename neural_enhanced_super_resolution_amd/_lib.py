@@ -25,6 +25,8 @@ SIGNATURES = {
     "nesr_num_tensors": (_c.c_int, [_c.c_void_p]),
     "nesr_forward": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "nesr_forward_u8": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p]),
+    "nesr_forward_ragged": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int), _c.c_void_p, _c.c_void_p]),
+    "nesr_set_size_independent": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "nesr_workspace_bytes": (_c.c_size_t, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int]),
     "nesr_reserve": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int]),
     "nesr_preferred_batch": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int]),

@@ -133,6 +133,13 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_bf16_xl_kernel(ConvArgs
     tile -= n * tiles_x * tiles_y;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int y0 = ty * TH, x0 = tx * TW;
+    // this image's own size inside its h x w slot (ragged batches: a frame's tiles of different sizes in one launch)
+    int vh = a.h, vw = a.w_;
+    if (a.rag_n) {
+        vh = (int)a.rag_h[n] << a.rag_shift;
+        vw = (int)a.rag_w[n] << a.rag_shift;
+        if (y0 >= vh || x0 >= vw) return;          // the whole workgroup: nothing of this tile belongs to the image
+    }
 
     // ---- LDS-DMA sources.  LDS item k of an input slot = padded pixel k>>1, 16-byte slot k&1; it
     // holds channel half (k&1) ^ bit3(padded column) of that pixel's chunk.
@@ -149,7 +156,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_bf16_xl_kernel(ConvArgs
             const int half = (k & 1) ^ ((px >> 3) & 1);
             const int Y = y0 - 1 + py, X = x0 - 1 + px;
             const bool has = k < IN_ITEMS;
-            const bool ok = has && Y >= 0 && Y < a.h && X >= 0 && X < a.w_;
+            const bool ok = has && Y >= 0 && Y < vh && X >= 0 && X < vw;
             const int sy = ok ? (Y >> a.up) : 0, sx = ok ? (X >> a.up) : 0;
             isrc[i] = ok ? in + ((((size_t)n * a.in_h + sy) * a.in_w + sx) * a.in_map.pix) * 2 + half * 16 : zero_page;
             live |= ok ? (1u << i) : 0u;
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_bf16_xl_kernel(ConvArgs
     for (int dx = 0; dx < 3; ++dx) p_off[dx] = ((4 * wave) * PW + m + dx) * 32 + ((hh ^ (((m + dx) >> 3) & 1)) << 4);
     const int w_off = hh * (32 * NT) + m;             // item index inside a weight slot
     // waves whose 4 rows are all below the image do no arithmetic (edge tiles), but still stage and barrier
-    const bool active = (y0 + 4 * wave) < a.h;
+    const bool active = (y0 + 4 * wave) < vh;
 
     f32x16 acc[4][NT];
 #pragma unroll
@@ -280,7 +287,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_bf16_xl_kernel(ConvArgs
 
     // ---- epilogue: lane = pixel column m of rows 4*wave + r; regs = 4-channel runs 8g + 4hh (+32t)
     const int X = x0 + m;
-    const bool xok = X < a.w_;
+    const bool xok = X < vw;
     const int Xc = xok ? X : 0;
     const uint16_t* res1 = static_cast<const uint16_t*>(a.res1);
     const uint16_t* res2 = static_cast<const uint16_t*>(a.res2);
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(64 * WAVES, 2) void conv3x3_bf16_xl_kernel(ConvArgs
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int Y = y0 + 4 * wave + r;
-        const bool valid = xok && Y < a.h;
+        const bool valid = xok && Y < vh;
         const size_t pix = ((size_t)n * a.h + (Y < a.h ? Y : 0)) * a.w_ + Xc;
         auto at = [&](const Map& mp, int c) -> size_t { return (size_t)(c >> 4) * mp.chunk + pix * mp.pix + (c & 15); };
         f32x4 r1[NT][4], r2[NT][4];

@@ -549,8 +549,9 @@ hipError_t launch_conv3x3_bf16(const ConvArgs& a, hipStream_t s) {
     }();
     const bool large = (long)a.h * a.w_ > 256L * 256L;
     if (a.zeros) {
-        if (mode == 3 || (mode == 0 && large)) return launch_conv3x3_bf16_xl(a, s);
+        if (mode == 3 || (mode == 0 && large) || a.rag_n || a.size_independent) return launch_conv3x3_bf16_xl(a, s);
     }
+    if (a.rag_n) return hipErrorInvalidValue;   // only the large-tile kernel knows about ragged batches
     return launch<true>(a, s);
 }
 

@@ -78,6 +78,10 @@ struct nesr_ctx {
     unsigned* last_sync = nullptr;   // abort word of the most recent persistent launch   // device copy of the trunk's layer table (persistent trunk kernel)
     int trunk_mode = 0;              // 0 auto, 1 per-layer launches, 2 persistent kernel
     int shared_device = 0;           // nesr_set_concurrent: other contexts run on the device at the same time
+    int size_independent = 0;        // nesr_set_size_independent: kernel choice must not depend on the image size
+    // the ragged batch being evaluated (nesr_forward_ragged): internal-resolution sizes of its images
+    int rag_n = 0, rag_base_h = 0;
+    unsigned short rag_h[nesr::RAG_MAX], rag_w[nesr::RAG_MAX];
     unsigned* d_status = nullptr;    // [0] sticky range word of the f16-pair path (ConvArgs::status), [1] abort word of the fused
                                      // dense-block kernel, [64..] its per-tile progress words
     unsigned rdb_epoch = 0;          // fused dense-block launches: progress values of a launch are epoch+1 .. epoch+4
@@ -173,6 +177,13 @@ ConvArgs base_args(const nesr_ctx* c, const Layer& L, int N, int h, int w) {
     a.s1 = a.s2 = 1.f;
     a.cout_real = 0;
     a.shared_device = c->shared_device;
+    a.size_independent = c->size_independent;
+    if (c->rag_n) {
+        a.rag_n = c->rag_n;
+        a.rag_shift = h == c->rag_base_h ? 0 : (h == 2 * c->rag_base_h ? 1 : 2);
+        std::memcpy(a.rag_h, c->rag_h, sizeof(a.rag_h));
+        std::memcpy(a.rag_w, c->rag_w, sizeof(a.rag_w));
+    }
     a.status = c->dtype == NESR_DTYPE_F32_SPLIT ? c->d_status : nullptr;
     return a;
 }
@@ -647,6 +658,34 @@ int nesr_forward(nesr_ctx* c, const void* x_dev, int N, int C, int H, int W, voi
     if (!c || !x_dev || !y_dev) return fail(NESR_ERR_ARG, "null argument");
     return run_forward(c, static_cast<const float*>(x_dev), nullptr, 0, N, C, H, W, static_cast<float*>(y_dev), nullptr, 0,
                        static_cast<hipStream_t>(stream));
+}
+
+int nesr_forward_ragged(nesr_ctx* c, const void* x_dev, int N, int C, int H, int W, const int* hw, void* y_dev, void* stream) {
+    if (!c || !x_dev || !y_dev || !hw) return fail(NESR_ERR_ARG, "null argument");
+    if (c->dtype != NESR_DTYPE_BF16) return fail(NESR_ERR_ARG, "nesr_forward_ragged: compute dtype bf16 only (the other forms batch equal-sized images)");
+    if (N < 1 || N > nesr::RAG_MAX) return fail(NESR_ERR_ARG, "nesr_forward_ragged: 1.." + std::to_string(nesr::RAG_MAX) + " images per call");
+    const int u = c->ufac();
+    if (H % u || W % u || H / u > 16383 || W / u > 16383) return fail(NESR_ERR_ARG, "nesr_forward_ragged: slot size");
+    for (int i = 0; i < N; ++i) {
+        const int h = hw[2 * i], w = hw[2 * i + 1];
+        if (h < 1 || w < 1 || h > H || w > W || h % u || w % u)
+            return fail(NESR_ERR_ARG, "nesr_forward_ragged: image " + std::to_string(i) + " is " + std::to_string(h) + "x" + std::to_string(w) +
+                                          ", slot " + std::to_string(H) + "x" + std::to_string(W) + ", unshuffle " + std::to_string(u));
+        c->rag_h[i] = (unsigned short)(h / u);
+        c->rag_w[i] = (unsigned short)(w / u);
+    }
+    c->rag_n = N;
+    c->rag_base_h = H / u;
+    const int rc = run_forward(c, static_cast<const float*>(x_dev), nullptr, 0, N, C, H, W, static_cast<float*>(y_dev), nullptr, 0,
+                               static_cast<hipStream_t>(stream));
+    c->rag_n = 0;
+    return rc;
+}
+
+int nesr_set_size_independent(nesr_ctx* c, int on) {
+    if (!c) return fail(NESR_ERR_ARG, "null ctx");
+    c->size_independent = on ? 1 : 0;
+    return NESR_OK;
 }
 
 int nesr_forward_u8(nesr_ctx* c, const uint8_t* in_hwc_dev, int H, int W, uint8_t* out_hwc_dev, int flip_rgb,

@@ -33,6 +33,8 @@ inline hipError_t ensure_dynamic_lds(const void* kernel, size_t bytes, unsigned 
     return e;
 }
 
+constexpr int RAG_MAX = 64;   // images per ragged batch
+
 // One fused 3x3 / stride 1 / zero-pad 1 convolution (torch.cat-free dense block: conv k reads
 // channels [0, cin) and writes channels [out_coff, out_coff + coutp) of the same buffer).
 struct ConvArgs {
@@ -77,6 +79,15 @@ struct ConvArgs {
     // host-side hint, not read by kernels: other contexts' launches share the device with this one (frames or tile
     // groups in flight on several streams) -- prefer kernel forms whose workgroups leave room on a CU
     int shared_device;
+    // Images of different sizes in one batch (nesr_forward_ragged: the tiles of a frame, whose edge tiles are smaller):
+    // image i occupies the top-left (rag_h[i] << rag_shift) x (rag_w[i] << rag_shift) pixels of its h x w slot, the rest
+    // of the slot is neither read (it counts as the zero padding) nor written.  rag_n = 0: every image is h x w.  The
+    // sizes travel in the kernel arguments (no device table, no copy to order).  conv3x3_bf16_xl_kernel only.
+    int rag_n, rag_shift;
+    // host-side hint: choose the kernel by arithmetic only, never by image size (nesr_set_size_independent): a tile's bits
+    // must not depend on whether it was evaluated alone or inside a ragged batch
+    int size_independent;
+    unsigned short rag_h[RAG_MAX], rag_w[RAG_MAX];
 };
 
 // f32 path: v_mfma_f32_32x32x2_f32 implicit GEMM (conv3x3_f32.hip)

@@ -97,6 +97,10 @@ class RealESRGANer:
         self.half = half
         self.tile_batch = 24  # upper bound on equal-shaped tiles per forward call (1 = upstream's serial loop)
         self.tile_streams = 3 # HIP streams (context replicas) the shape groups of one frame are spread over
+        self.ragged_tiles = False # bf16: tiles of different shapes in one batch per layer (see _run_tiles_ragged; measured: no faster)
+        self.ragged_batch = 64    # tiles per ragged batch
+        self.small_job_tiles = 12   # a call with at most this many tiles (a rank's share of a sharded frame) ...
+        self.small_job_streams = 5  # ... is spread over this many streams, its batches split until every stream has one
 
         if gpu_id:
             self.device = torch.device(f"cuda:{gpu_id}" if torch.cuda.is_available() else "cpu") if device is None else device
@@ -128,6 +132,10 @@ class RealESRGANer:
         self.model = model.to(self.device)
         if self.half:
             self.model = self.model.half()
+        if isinstance(self.model, RRDBNet) and self.tile_size > 0 and self.model.compute_dtype == "bf16":
+            # a tiling wrapper batches tiles of different shapes (ragged batches): a tile's values must not depend on how it
+            # was batched, nor on whether model(tile) was called directly -- kernels are chosen by arithmetic only
+            self.model.size_independent = True
 
     @staticmethod
     def _adapt_declared_scale(model, state):
@@ -224,24 +232,50 @@ class RealESRGANer:
             groups.setdefault((t[1] - t[0], t[3] - t[2]), []).append(t)
         order = sorted(groups.items(), key=lambda kv: -kv[0][0] * kv[0][1] * len(kv[1]))
         hip = isinstance(self.model, RRDBNet) and img.device.type == "cuda"
-        nstreams = max(1, int(self.tile_streams)) if hip and len(order) > 1 else 1
-
-        def run_group(shape, ts, slot):
+        if hip and len(order) > 1 and img.shape[0] == 1 and self.ragged_tiles and self.model.compute_dtype == "bf16":
+            return self._run_tiles_ragged(img, tiles, sink)
+        # Batches of equal-shaped windows, one shape group per stream.  A small job (a rank's share of a sharded frame: five
+        # tiles of an 8-way split 4K frame, often of one shape) is spread wider: every batch its own unit, the largest
+        # halved until each of `small_job_streams` streams has one -- one stream would run 351 launches of a few hundred
+        # workgroups each, five overlap their prologues, epilogues and tails (measured on one GPU with an 8-rank share:
+        # 25.6 -> 16.9 ms for the slowest rank)
+        units = []                                    # a unit = the batches of one shape group, run in order on one stream
+        for shape, ts in order:
             nb = self.batch_for(shape[0], shape[1], len(ts)) if img.shape[0] == 1 else 1
-            for i in range(0, len(ts), nb):
-                chunk = ts[i:i + nb]
-                if len(chunk) == 1:
-                    inp = img[:, :, chunk[0][0]:chunk[0][1], chunk[0][2]:chunk[0][3]]
-                else:
-                    inp = torch.cat([img[:, :, t[0]:t[1], t[2]:t[3]] for t in chunk], 0)
-                with torch.no_grad():
-                    out = self.model(inp, slot=slot) if hip else self.model(inp)
-                for j, t in enumerate(chunk):
-                    sink(t[4], out[j:j + 1] if len(chunk) > 1 else out)
+            units.append([ts[i:i + nb] for i in range(0, len(ts), nb)])
+        nstreams = 1
+        if hip and len(tiles) > 1:
+            nstreams = max(1, int(self.tile_streams))
+            if len(tiles) <= self.small_job_tiles:
+                nstreams = min(max(nstreams, int(self.small_job_streams)), len(tiles))
+                units = [[b] for u in units for b in u]
+                while len(units) < nstreams:
+                    k = max(range(len(units)), key=lambda i: len(units[i][0]))
+                    b = units[k][0]
+                    if len(b) < 2:
+                        break
+                    units[k:k + 1] = [[b[:(len(b) + 1) // 2]], [b[(len(b) + 1) // 2:]]]
+            elif len(units) == 1:
+                nstreams = 1
 
+        def area(b):
+            return (b[0][1] - b[0][0]) * (b[0][3] - b[0][2]) * len(b)
+
+        def run_batch(chunk, slot):
+            if len(chunk) == 1:
+                inp = img[:, :, chunk[0][0]:chunk[0][1], chunk[0][2]:chunk[0][3]]
+            else:
+                inp = torch.cat([img[:, :, t[0]:t[1], t[2]:t[3]] for t in chunk], 0)
+            with torch.no_grad():
+                out = self.model(inp, slot=slot) if hip else self.model(inp)
+            for j, t in enumerate(chunk):
+                sink(t[4], out[j:j + 1] if len(chunk) > 1 else out)
+
+        units.sort(key=lambda u: -sum(area(b) for b in u))
         if nstreams == 1:
-            for shape, ts in order:
-                run_group(shape, ts, 0)
+            for u in units:
+                for b in u:
+                    run_batch(b, 0)
             return
         main = torch.cuda.current_stream(img.device)
         if not hasattr(self, "_side_streams") or len(self._side_streams) < nstreams - 1:
@@ -250,13 +284,67 @@ class RealESRGANer:
         for s in streams[1:]:
             s.wait_stream(main)                       # img / the output canvas were produced on the main stream
         load = [0] * nstreams
-        for shape, ts in order:                       # largest group first, each to the least-loaded stream
+        for u in units:                               # largest unit first, each to the least-loaded stream
             k = load.index(min(load))
-            load[k] += shape[0] * shape[1] * len(ts)
+            load[k] += sum(area(b) for b in u)
             with torch.cuda.stream(streams[k]):
-                run_group(shape, ts, k)
+                for b in u:
+                    run_batch(b, k)
         for s in streams[1:]:
             main.wait_stream(s)
+
+    def _run_tiles_ragged(self, img, tiles, sink):
+        """All windows of a frame, whatever their shapes, in `tile_streams` ragged batches that run side by side: every
+        window lies in the top-left corner of an equal-sized slot and the kernels take each image's own size from the
+        call (nesr_forward_ragged).  Against one batch per tile shape: the small edge-tile groups were latency-bound
+        launches of a few workgroups -- and with the tiles sharded over ranks every group shrinks further -- while
+        batches of mixed sizes keep every launch large; several batches on their own streams (context replicas) fill
+        each other's prologues and epilogues as the shape groups did.  bf16 only; the model is size_independent, so a
+        window's values are the ones model(window) gives it alone."""
+        if not self.model.size_independent:
+            self.model.size_independent = True
+        cap = max(1, min(self.model.RAGGED_MAX, int(self.ragged_batch)))
+        nstreams = max(1, min(int(self.tile_streams), len(tiles)))
+        # largest first, each to the least-loaded batch; a batch that is full opens another one on the same stream
+        ts = sorted(tiles, key=lambda t: -(t[1] - t[0]) * (t[3] - t[2]))
+        lanes = [[[]] for _ in range(nstreams)]
+        load = [0] * nstreams
+        for t in ts:
+            k = load.index(min(load))
+            load[k] += (t[1] - t[0]) * (t[3] - t[2])
+            if len(lanes[k][-1]) == cap:
+                lanes[k].append([])
+            lanes[k][-1].append(t)
+
+        def run_batch(chunk, slot):
+            H = max(t[1] - t[0] for t in chunk)
+            W = max(t[3] - t[2] for t in chunk)
+            x = img.new_zeros((len(chunk), img.shape[1], H, W))
+            for j, t in enumerate(chunk):
+                x[j, :, :t[1] - t[0], :t[3] - t[2]] = img[0, :, t[0]:t[1], t[2]:t[3]]
+            with torch.no_grad():
+                out = self.model.forward_ragged(x, [(t[1] - t[0], t[3] - t[2]) for t in chunk], slot=slot)
+            s = out.shape[2] // H
+            for j, t in enumerate(chunk):
+                sink(t[4], out[j:j + 1, :, :(t[1] - t[0]) * s, :(t[3] - t[2]) * s])
+
+        if nstreams == 1:
+            for chunk in lanes[0]:
+                run_batch(chunk, 0)
+            return
+        main = torch.cuda.current_stream(img.device)
+        if not hasattr(self, "_side_streams") or len(self._side_streams) < nstreams - 1:
+            self._side_streams = [torch.cuda.Stream(device=img.device) for _ in range(nstreams - 1)]
+        streams = [main] + self._side_streams[:nstreams - 1]
+        for st in streams[1:]:
+            st.wait_stream(main)
+        for k in range(nstreams):
+            with torch.cuda.stream(streams[k]):
+                for chunk in lanes[k]:
+                    if chunk:
+                        run_batch(chunk, k)
+        for st in streams[1:]:
+            main.wait_stream(st)
 
     def tile_process(self):
         """Runs the network on overlapping tiles and pastes the un-padded centres (upstream

@@ -190,6 +190,8 @@ class RRDBNet(nn.Module):
         _lib.check(_lib.load().nesr_create(ctypes.byref(handle), index, conv_first_in_ch(self.num_in_ch, self.scale),
                                            unshuffle, self.num_feat, self.num_block, self.num_grow_ch, self.num_out_ch, code),
                    "nesr_create")
+        if getattr(self, "_size_independent", False):
+            _lib.check(_lib.load().nesr_set_size_independent(handle, 1), "nesr_set_size_independent")
         return handle
 
     def _context(self, device: torch.device, slot: int = 0):
@@ -221,6 +223,21 @@ class RRDBNet(nn.Module):
             self._upload(self._ctx[0])
             self._dirty = False
         return self._ctx[0]
+
+    RAGGED_MAX = 64          # images per forward_ragged call (nesr::RAG_MAX)
+
+    @property
+    def size_independent(self):
+        """True: kernels are chosen by arithmetic only, never by image size, so an image has the same bits alone, in an
+        equal-shape batch and in a ragged batch (include/nesr_hip.h: nesr_set_size_independent)."""
+        return getattr(self, "_size_independent", False)
+
+    @size_independent.setter
+    def size_independent(self, on):
+        self._size_independent = bool(on)
+        handles = ([self._ctx] if self._ctx is not None else []) + list(self._extra.values())
+        for h in handles:
+            _lib.check(_lib.load().nesr_set_size_independent(h[0], 1 if on else 0), "nesr_set_size_independent")
 
     # ------------------------------------------------------------------ forward
     def out_scale(self):
@@ -254,6 +271,31 @@ class RRDBNet(nn.Module):
             stream = torch.cuda.current_stream(xf.device).cuda_stream
             _lib.check(_lib.load().nesr_forward(ctx, ctypes.c_void_p(xf.data_ptr()), n, c, h, w,
                                                 ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(stream)), "nesr_forward")
+        return y if in_dtype == torch.float32 else y.to(in_dtype)
+
+    @torch.no_grad()
+    def forward_ragged(self, x, sizes, slot: int = 0):
+        """Images of different sizes in one batch (the tiles of a frame: realesrgan's tile_process as
+        standalone/direct_esrgan.py:118-127 configures it cuts interior tiles of 532 x 532 and smaller edge tiles).
+        x: [N, num_in_ch, H, W] float on a ROCm device, image i in the top-left sizes[i] = (h_i, w_i) pixels of slot i
+        (the rest of a slot is ignored); returns [N, num_out_ch, H*s, W*s] whose slot i holds image i's output in its
+        top-left h_i*s x w_i*s pixels (the rest is unspecified).  Every image gets the values forward() gives it alone
+        on a model with size_independent = True.  compute_dtype "bf16" only; N <= RAGGED_MAX."""
+        self._require_cuda(x)
+        if x.dim() != 4 or len(sizes) != x.shape[0]:
+            raise ValueError(f"expected NCHW input and one (h, w) per image, got {tuple(x.shape)} and {len(sizes)} sizes")
+        in_dtype = x.dtype
+        xf = x.to(torch.float32).contiguous()
+        n, c, h, w = xf.shape
+        hw = (ctypes.c_int * (2 * n))(*[int(v) for pair in sizes for v in pair])
+        s = self.out_scale()
+        self.calls += 1
+        with torch.cuda.device(xf.device):
+            ctx = self._context(xf.device, slot)
+            y = torch.empty((n, self.num_out_ch, h * s, w * s), dtype=torch.float32, device=xf.device)
+            stream = torch.cuda.current_stream(xf.device).cuda_stream
+            _lib.check(_lib.load().nesr_forward_ragged(ctx, ctypes.c_void_p(xf.data_ptr()), n, c, h, w, hw,
+                                                       ctypes.c_void_p(y.data_ptr()), ctypes.c_void_p(stream)), "nesr_forward_ragged")
         return y if in_dtype == torch.float32 else y.to(in_dtype)
 
     @torch.no_grad()
