@@ -70,20 +70,8 @@ constexpr int W_ITEMS = 9 * 2 * 2 * 32;   // 16-byte items of one 32-cout weight
 constexpr int W_BYTES = W_ITEMS * 16;
 constexpr int ISLOTS = 2;                 // two-slot rings: every wait is vmcnt(0)
 
-// LDS-DMA from inline asm (see conv3x3_bf16.hip): not counted by hipcc, waited for by hand.
-__device__ __forceinline__ void glds16_asm(const char* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
-}
-// the same with a scalar 64-bit base and an unsigned 32-bit per-lane byte offset
+// LDS-DMA from inline asm (see conv3x3_bf16.hip): not counted by hipcc, waited for by hand; scalar 64-bit base and an
+// unsigned 32-bit per-lane byte offset
 __device__ __forceinline__ void glds16_s(const char* sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
     asm volatile(
@@ -108,7 +96,6 @@ __device__ __forceinline__ void store16(uint16_t* p, uint4 v) {
 }
 
 constexpr float LO_SCALE = 2048.f, LO_INV = 1.f / 2048.f;   // lo is stored as f16((x - hi) * 2^11)
-constexpr float F16_MAX = 65504.f;
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -133,13 +120,6 @@ __device__ __forceinline__ void split4(f32x4 v, uint2& hi, uint2& lo, bool& bad)
     split2(v[0], v[1], hi.x, lo.x, bits);
     split2(v[2], v[3], hi.y, lo.y, bits);
     bad |= (bits & 0x80008000u) != 0u;
-}
-// 4 consecutive channels of a split feature map: p -> hi halves, lo halves 16 elements on
-__device__ __forceinline__ f32x4 ld4_split(const uint16_t* p) {
-    const f16x4 h = *reinterpret_cast<const f16x4*>(p);
-    const f16x4 l = *reinterpret_cast<const f16x4*>(p + 16);
-    return f32x4{fmaf((float)l[0], LO_INV, (float)h[0]), fmaf((float)l[1], LO_INV, (float)h[1]),
-                 fmaf((float)l[2], LO_INV, (float)h[2]), fmaf((float)l[3], LO_INV, (float)h[3])};
 }
 
 
@@ -568,10 +548,7 @@ __device__ __forceinline__ void glds16_s_sc1(const char* sbase, unsigned voff, u
         : "v"(voff), "s"(sbase), "s"(lds_dst)
         : "memory");
 }
-__device__ __forceinline__ void store16_wt(uint16_t* p, uint4 v) {   // write-through: visible device-wide once vmcnt retires it
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(f32x4, v)) : "memory");
-}
-__device__ __forceinline__ void store16_wt_s(const char* sbase, unsigned voff, uint4 v) {   // the same, wave-uniform base + 32-bit lane offset
+__device__ __forceinline__ void store16_wt_s(const char* sbase, unsigned voff, uint4 v) {   // write-through (visible device-wide once vmcnt retires it): wave-uniform base + 32-bit lane offset
     asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" ::"v"(voff), "v"(__builtin_bit_cast(f32x4, v)), "s"(sbase) : "memory");
 }
 
@@ -1207,7 +1184,7 @@ hipError_t launch_conv3x3_f16x2(const ConvArgs& a, hipStream_t s) {
     // fills those gaps and the extra waves only cost occupancy (measured +21 % on 6 tiles of 532x532).
     static const int cus = [] {
         int dev = 0, n = 256;
-        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
         return n;
     }();
     static const int dmaw = [] { const char* e = getenv("NESR_SPLIT_DMAW"); return e ? atoi(e) : -1; }();
