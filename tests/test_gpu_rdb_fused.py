@@ -101,3 +101,23 @@ def test_frame_too_large_for_the_cus_takes_the_per_layer_path(cuda_device):
     n_small, n_large = _launches(net, x_small), _launches(net, x_large)
     assert n_large - n_small == 4 * 3, (n_small, n_large)
     net.check_status()
+
+
+def test_fused_full_frame_repeats_are_bitwise_stable(cuda_device):
+    """The 512 x 512 bench frame: 256 tiles, one per compute unit, every tile boundary an inter-workgroup hand-off (x1..x4
+    halos through sc1 stores, a progress word, sc1 LDS-DMA loads) and one row of tiles in eight an inter-XCD one.  A stale
+    halo read would show as a run that differs from the per-layer evaluation: 150 forwards, each compared bit for bit."""
+    from neural_enhanced_super_resolution_amd.synth import synthetic_state_dict
+    sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=2, num_block=23)
+    x = torch.rand(1, 3, 512, 512, generator=torch.Generator().manual_seed(11)).to(cuda_device)
+    want = _net(sd, 23, False)(x)
+    fused = _net(sd, 23, True)
+    assert _launches(fused, x) == 3 * 23
+    bad = 0
+    for i in range(150):
+        if i % 7 == 0:
+            torch.cuda.synchronize()                      # vary what is in flight when a forward starts
+        got = fused(x)
+        bad += 0 if torch.equal(got, want) else 1
+    fused.check_status()
+    assert bad == 0, f"{bad} of 150 fused forwards differ from the per-layer evaluation"
