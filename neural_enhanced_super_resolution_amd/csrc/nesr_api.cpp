@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -88,6 +89,20 @@ struct nesr_ctx {
     int rdb_mode = -1;               // NESR_RDB_FUSE: -1 auto (fuse when every tile gets its own CU), 0 never
     int cus = 256;
     unsigned* h_status = nullptr;    // pinned landing word of nesr_check_range
+    // bf16 dense blocks with the working set resident in LDS (rdb_bf16_strip.hip)
+    char* d_strip = nullptr;         // per dense block: weight stream (strip_weight_bytes()) + 192 f32 of bias
+    size_t strip_stride = 0;
+    int strip_mode = -1;             // NESR_STRIP: -1 auto (size-independent contexts, or batches that fill the device), 0 never, 1 wherever it applies
+    unsigned strip_epoch = 0;
+    bool strip_used = false;         // a strip launch went out since the last status check
+    unsigned long long strip_timeout_ticks = 20000000ull;   // 200 ms of s_memrealtime
+    struct StripPlan {
+        std::vector<int> key;        // N, H, W, then (h, w) of every image
+        void* d_items = nullptr; int* d_first = nullptr; char* d_xch = nullptr;
+        int grid = 0, smax = 0, makespan = 0;
+        double efficiency = 0.0;
+    };
+    std::vector<StripPlan> strip_plans;
     FwState band;                    // the banded evaluation in progress (nesr_band_*)
     bool band_valid = false;
     // kernel timing hook
@@ -200,6 +215,95 @@ Map make_map(int kind, int channels, size_t pixels) {
 
 double conv_flops(const Layer& L, double pixels) { return 2.0 * 9.0 * L.cin * L.cout * pixels; }
 
+// ---- persistent kernels need the device to themselves: every workgroup of rdb_f16x2_kernel / rdb_bf16_strip_kernel waits for
+// other workgroups of the same launch, so two such launches that share the compute units (two contexts on two streams) can
+// each hold CUs the other one's missing workgroups need.  Within a process they are therefore serialised per device:
+// a stream that is about to launch one first waits for the event recorded behind the previous holder's last launch.
+// (Across processes nothing can order them: the kernels bound their waits and raise an abort word, nesr_check_range.)
+struct DeviceLease {
+    std::mutex mu;
+    hipEvent_t ev = nullptr;
+    hipStream_t owner = nullptr;
+    const nesr_ctx* owner_ctx = nullptr;
+    bool pending = false;
+};
+DeviceLease g_lease[64];
+
+int lease_acquire(const nesr_ctx* c, hipStream_t s) {
+    if (c->device < 0 || c->device >= 64) return NESR_OK;
+    DeviceLease& L = g_lease[c->device];
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (L.pending && (L.owner_ctx != c || L.owner != s)) HIP_TRY(hipStreamWaitEvent(s, L.ev, 0));
+    return NESR_OK;
+}
+int lease_release(const nesr_ctx* c, hipStream_t s) {
+    if (c->device < 0 || c->device >= 64) return NESR_OK;
+    DeviceLease& L = g_lease[c->device];
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (!L.ev) HIP_TRY(hipEventCreateWithFlags(&L.ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(L.ev, s));
+    L.owner = s;
+    L.owner_ctx = c;
+    L.pending = true;
+    return NESR_OK;
+}
+void lease_forget(const nesr_ctx* c) {
+    if (c->device < 0 || c->device >= 64) return;
+    DeviceLease& L = g_lease[c->device];
+    std::lock_guard<std::mutex> lock(L.mu);
+    if (L.owner_ctx == c) { L.owner_ctx = nullptr; L.owner = nullptr; }   // the event stays valid: later holders still wait for it
+}
+
+void free_strip_plans(nesr_ctx* c) {
+    for (auto& P : c->strip_plans) {
+        if (P.d_items) (void)hipFree(P.d_items);
+        if (P.d_first) (void)hipFree(P.d_first);
+        if (P.d_xch) (void)hipFree(P.d_xch);
+    }
+    c->strip_plans.clear();
+}
+
+// the strip schedule + mailboxes of one batch geometry (cached: a video stream asks for the same one every frame)
+int strip_plan_for(nesr_ctx* c, int N, int h, int w, const nesr_ctx::StripPlan** out) {
+    std::vector<int> key{N, h, w};
+    std::vector<int> hw(2 * (size_t)N);
+    for (int i = 0; i < N; ++i) {
+        hw[2 * i] = c->rag_n ? c->rag_h[i] : h;
+        hw[2 * i + 1] = c->rag_n ? c->rag_w[i] : w;
+    }
+    key.insert(key.end(), hw.begin(), hw.end());
+    for (const auto& P : c->strip_plans)
+        if (P.key == key) { *out = &P; return NESR_OK; }
+    if (c->strip_plans.size() >= 32) {
+        HIP_TRY(hipDeviceSynchronize());
+        free_strip_plans(c);
+    }
+    nesr_ctx::StripPlan P;
+    P.key = key;
+    const StripSchedule S = strip_schedule(N, hw.data(), c->cus);
+    P.makespan = S.makespan;
+    if (S.makespan > 0 && S.makespan < 250) {       // tags hold position * 8 + layer below 2048
+        P.grid = S.grid; P.smax = S.smax; P.efficiency = S.efficiency;
+        const size_t xb = (size_t)N * S.smax * STRIP_XCH_BYTES;
+        HIP_TRY(hipMalloc(&P.d_items, S.items.size() * 4));
+        HIP_TRY(hipMalloc((void**)&P.d_first, S.wg_first.size() * 4));
+        HIP_TRY(hipMalloc((void**)&P.d_xch, xb));
+        HIP_TRY(hipMemcpy(P.d_items, S.items.data(), S.items.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(P.d_first, S.wg_first.data(), S.wg_first.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(P.d_xch, 0, xb));
+    } else {
+        P.makespan = -1;
+    }
+    c->strip_plans.push_back(std::move(P));
+    *out = &c->strip_plans.back();
+    return NESR_OK;
+}
+
+// does this evaluation's trunk run as persistent (lease-holding) launches?
+bool strip_wanted(const nesr_ctx* c) {
+    return c->dtype == NESR_DTYPE_BF16 && c->d_strip && c->strip_mode != 0 && c->nf == 64 && c->gc == 32;
+}
+
 // ---- the forward graph in stages (whole-frame forward = all of them in order; the banded multi-GPU mode
 // runs them one at a time with a row exchange in between)
 int fw_setup(nesr_ctx* c, int N, int C, int H, int W, FwState& F) {
@@ -263,6 +367,40 @@ int fw_rdb(nesr_ctx* c, const FwState& F, int b, int r, hipStream_t s, int phase
     const bool ranged = phase >= 0 && c->dtype == NESR_DTYPE_F32_SPLIT && F.N == 1 && F.h >= top + bottom + 2 * edge;
     if (phase == 1 && !ranged) return NESR_OK;
     if (phase >= 0 && !ranged) phase = -1;
+    // bf16: the dense block with its working set resident in LDS (rdb_bf16_strip_kernel), whenever the context is
+    // size-independent (a tiling wrapper: one arithmetic for every tile, however it is batched) or the batch fills the device
+    if (phase < 0 && strip_wanted(c)) {
+        const nesr_ctx::StripPlan* P = nullptr;
+        int rc = strip_plan_for(c, F.N, F.h, F.w, &P);
+        if (rc) return rc;
+        if (P->makespan > 0 && (c->strip_mode == 1 || c->size_independent || P->efficiency >= 0.55)) {
+            StripLaunch L;
+            std::memset(&L, 0, sizeof(L));
+            L.cur = cur;
+            L.chunk_bytes = F.m_t.chunk * 2;
+            L.out = r < 2 ? F.buf[r + 1] : F.buf[0];
+            L.res2 = r < 2 ? nullptr : F.buf[0];
+            L.s1 = 0.2f; L.s2 = 0.2f;
+            const char* blk = c->d_strip + (size_t)(b * 3 + r) * c->strip_stride;
+            L.wstream = blk;
+            L.bias = reinterpret_cast<const float*>(blk + strip_weight_bytes());
+            L.H = F.h; L.W = F.w;
+            L.items = P->d_items; L.wg_first = P->d_first; L.grid = P->grid; L.smax = P->smax; L.xch = P->d_xch;
+            c->strip_epoch += 2048;
+            L.epoch = c->strip_epoch;
+            L.abort_flag = c->d_status + 2;
+            L.timeout_ticks = c->strip_timeout_ticks;
+            HIP_TRY(launch_rdb_bf16_strip(L, s));
+            c->strip_used = true;
+            if (c->timing) {
+                double px_real = 0.0;      // ragged batches: the images' own pixels
+                for (int i = 0; i < F.N; ++i) px_real += c->rag_n ? (double)c->rag_h[i] * c->rag_w[i] : (double)F.h * F.w;
+                for (int k = 0; k < 5; ++k) c->timed_flops += conv_flops(c->layers[layer_id(c, b, r, k)], px_real);
+                c->timed_launches += 1;
+            }
+            return NESR_OK;
+        }
+    }
     // small frames, f16-pair form: the whole dense block in one launch (rdb_f16x2_kernel).  Every tile needs its own
     // resident workgroup, so the frame's tiles must fit the compute units and the device must be this context's
     // (frames in flight on other streams would compete for the one workgroup slot per CU).
@@ -424,9 +562,13 @@ int run_forward(nesr_ctx* c, const float* x_f32, const uint8_t* x_u8, int flip, 
             c->timed_launches += 1;
         }
     } else {
+        // the fused dense-block kernels hold the device: serialised per device against other streams' (see DeviceLease)
+        const bool lease = (strip_wanted(c) || (c->dtype == NESR_DTYPE_F32_SPLIT && c->rdb_mode != 0 && !c->shared_device)) && c->nb > 0;
+        if (lease && (rc = lease_acquire(c, s))) return rc;
         for (int b = 0; b < c->nb; ++b)
             for (int r = 0; r < 3; ++r)
                 if ((rc = fw_rdb(c, F, b, r, s))) return rc;
+        if (lease && (rc = lease_release(c, s))) return rc;
     }
     if (c->timing) {
         HIP_TRY(hipEventRecord(ev1, s));
@@ -491,6 +633,8 @@ int nesr_create(nesr_ctx** out, int device_id, int conv_first_in_ch, int unshuff
     c->kgroup = (dtype == NESR_DTYPE_BF16 || dtype == NESR_DTYPE_F32_SPLIT) ? 16 : 8;
     if (const char* e = getenv("NESR_TRUNK")) c->trunk_mode = e[0] == 'l' ? 1 : (e[0] == 'p' ? 2 : 0);
     if (const char* e = getenv("NESR_RDB_FUSE")) c->rdb_mode = atoi(e);
+    if (const char* e = getenv("NESR_STRIP")) c->strip_mode = atoi(e);
+    if (const char* e = getenv("NESR_STRIP_TIMEOUT_MS")) c->strip_timeout_ticks = (unsigned long long)atoll(e) * 100000ull;
     (void)hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device_id);
     auto add = [&](const std::string& name, int cin, int cout) {
         Layer L;
@@ -614,6 +758,26 @@ int nesr_finalize_weights(nesr_ctx* c) {
         c->layers[i].d_w = c->d_weights + woff[i];
         c->layers[i].d_b = reinterpret_cast<float*>(c->d_weights + boff[i]);
         c->layers[i].d_ww = wwoff[i] ? c->d_weights + wwoff[i] : nullptr;
+    }
+    // bf16: every dense block's weights once more as the LDS-resident kernel's stream (rdb_bf16_strip.hip), + its 192 biases
+    if (c->d_strip) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->d_strip)); c->d_strip = nullptr; }
+    if (bf && c->nf == 64 && c->gc == 32 && c->nb > 0) {
+        c->strip_stride = align_up(strip_weight_bytes() + 192 * 4, 256);
+        std::vector<char> hs((size_t)c->nb * 3 * c->strip_stride, 0);
+        for (int b = 0; b < c->nb; ++b)
+            for (int r = 0; r < 3; ++r) {
+                char* blk = hs.data() + (size_t)(b * 3 + r) * c->strip_stride;
+                const float* w5[5];
+                float* bias = reinterpret_cast<float*>(blk + strip_weight_bytes());
+                for (int k = 0; k < 5; ++k) {
+                    const Layer& Ly = c->layers[layer_id(c, b, r, k)];
+                    w5[k] = Ly.w.data();
+                    std::memcpy(bias + 32 * k, Ly.b.data(), (size_t)Ly.cout * 4);
+                }
+                pack_strip_weights(w5, reinterpret_cast<uint16_t*>(blk));
+            }
+        HIP_TRY(hipMalloc((void**)&c->d_strip, hs.size()));
+        HIP_TRY(hipMemcpy(c->d_strip, hs.data(), hs.size(), hipMemcpyHostToDevice));
     }
     // layer table of the persistent trunk kernel (same wiring as the per-layer loop in run_forward)
     {
@@ -798,11 +962,23 @@ int nesr_check_status(nesr_ctx* c) {
 
 int nesr_check_range(nesr_ctx* c, void* stream) {
     if (!c) return fail(NESR_ERR_ARG, "null ctx");
-    if (c->dtype != NESR_DTYPE_F32_SPLIT) return NESR_OK;   // the other forms compute in formats with f32's range
+    if (c->dtype != NESR_DTYPE_F32_SPLIT && !c->strip_used) return NESR_OK;   // the other forms compute in formats with f32's range
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    HIP_TRY(hipMemcpyAsync(c->h_status, c->d_status, 8, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c->h_status, c->d_status, 12, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    c->strip_used = false;
+    if (c->h_status[2]) {
+        const unsigned code = c->h_status[2];      // 1 | layer waited for << 8 | workgroup << 16
+        HIP_TRY(hipMemsetAsync(c->d_status + 2, 0, 4, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        c->h_status[2] = 0;
+        return fail(NESR_ERR_HIP, "the LDS-resident dense-block kernel gave up waiting for a neighbouring strip's edge column (workgroup " +
+                                  std::to_string(code >> 16) + ", layer " + std::to_string((code >> 8) & 255u) +
+                                  ": its workgroups were not all resident -- another process's persistent kernel shares the device?); the "
+                                  "output of that forward is invalid. NESR_STRIP=0 selects per-layer launches");
+    }
+    if (c->dtype != NESR_DTYPE_F32_SPLIT) return NESR_OK;
     if (c->h_status[1]) {
         const unsigned code = c->h_status[1];      // 1 | chunk whose producer was waited for << 8 | tile << 16
         HIP_TRY(hipMemsetAsync(c->d_status, 0, 8, s));
@@ -833,6 +1009,9 @@ void nesr_destroy(nesr_ctx* c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->d_weights) (void)hipFree(c->d_weights);
     if (c->d_trunk) (void)hipFree(c->d_trunk);
+    if (c->d_strip) (void)hipFree(c->d_strip);
+    free_strip_plans(c);
+    lease_forget(c);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->h_status) (void)hipHostFree(c->h_status);
     delete c;

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace nesr {
 
 // Activation addressing.  Channels are grouped in K-groups of KG channels (8 for f32, 16 for
@@ -133,6 +135,34 @@ struct RdbLaunch {
 };
 int rdb_f16x2_tiles(int n, int h, int w);
 hipError_t launch_rdb_f16x2(const RdbLaunch& r, hipStream_t s);
+
+// bf16 dense block with the working set resident in LDS (rdb_bf16_strip.hip): a workgroup owns a 16-column strip of an
+// image and sweeps it top to bottom in positions of 12 rows; x1..x4 never leave the CU except for the strips' edge columns.
+constexpr int STRIP_BH = 12, STRIP_BW = 16;
+constexpr int STRIP_XCH_BYTES = 2 * 2 * 4 * STRIP_BH * 128;   // edge-column mailboxes of one strip
+struct StripSchedule {
+    std::vector<int> items;      // 4 ints per item: image, strip, image height, image width
+    std::vector<int> wg_first;   // [grid + 1]
+    int grid = 0, smax = 0, makespan = -1;
+    double efficiency = 0.0;     // strip positions of work / (compute units x makespan)
+};
+// n images of hw[2i] x hw[2i+1] internal pixels -> the packing (makespan < 0: the kernel does not apply)
+StripSchedule strip_schedule(int n, const int* hw, int cus);
+size_t strip_weight_bytes();
+void pack_strip_weights(const float* const w[5], uint16_t* dst);   // conv1..conv5 OIHW f32 of one dense block
+struct StripLaunch {
+    const void* cur; long long chunk_bytes; void* out; const void* res2;
+    float s1, s2;
+    const void* wstream; const float* bias;       // device: pack_strip_weights image, [192] f32 (conv1..4: 32 each, conv5: 64)
+    int H, W;                                     // slot geometry of the batch buffers
+    const void* items; const int* wg_first;       // device copies of the schedule
+    int grid, smax;
+    void* xch;                                    // n * smax * STRIP_XCH_BYTES
+    unsigned epoch;                               // strictly increasing by >= 2048 per launch
+    unsigned* abort_flag;
+    unsigned long long timeout_ticks;
+};
+hipError_t launch_rdb_bf16_strip(const StripLaunch& r, hipStream_t s);
 
 // Persistent trunk (conv3x3_mfma.hip): all dense-block convs of the 23 RRDBs in ONE cooperative
 // launch.  Workgroups keep their tiles from layer to layer and synchronise with their 8
