@@ -294,6 +294,9 @@ int strip_plan_for(nesr_ctx* c, int N, int h, int w, const nesr_ctx::StripPlan**
     } else {
         P.makespan = -1;
     }
+    if (getenv("NESR_STRIP_DEBUG"))
+        fprintf(stderr, "[nesr] strip plan: %d images (slot %dx%d): grid %d workgroups, makespan %d positions, efficiency %.3f\n", N, h, w, P.grid,
+                P.makespan, P.efficiency);
     c->strip_plans.push_back(std::move(P));
     *out = &c->strip_plans.back();
     return NESR_OK;

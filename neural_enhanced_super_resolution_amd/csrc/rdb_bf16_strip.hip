@@ -250,7 +250,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                     SSTAMP(MW + d, idx, 0);
                     // everything of this wave but the poll issued last step (its three loads are this wave's youngest) has
                     // landed; wave 3's x0 rows are only needed at the next position's first barrier
-                    if (d == 3) { if (idx == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                    if (d == 3) { if (idx == 0 || idx == NSTEP - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
                     else if (pending) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -305,29 +305,32 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                         }
                         wq7 += 3; wq7 -= wq7 >= NWS ? NWS : 0;
                         wq78 += 3; wq78 -= wq78 >= WPER ? WPER : 0;
-                    } else if (pos + 1 < npos && ((idx >= 18 && idx < 24) || (idx >= 6 && idx < 12))) {
-                        // (behind the other waves' weight DMAs of this step: a load that goes out to HBM holds up everything
-                        // queued behind it in this CU's memory pipeline for its whole latency)
-                        __builtin_amdgcn_s_sleep(10);
-                        if (idx >= 18 && idx < 24) {
-                            // the next position's 12 x0 rows, two per step, once conv5 has finished with x0 (its steps 0..3)
-#pragma unroll
-                            for (int k = 0; k < 2; ++k) {
-                                const int rr = 2 * (idx - 18) + k;
+                    } else if (pos + 1 < npos) {
+                        const int tk = idx == 1 ? 0 : idx == 4 ? 1 : idx == 8 ? 2 : idx == 13 ? 3 : idx == 16 ? 4 : -1;
+                        if (idx >= 18 && idx < 25) {
+                            // the next position's 12 x0 rows over seven steps (2, 2, 2, 2, 2, 1, 1), once conv5 has finished with x0 (its
+                            // steps 0..3); they have landed before the position's LAST barrier: behind it the MFMA waves already request
+                            // the next position's first fragments
+                            const int first = idx < 23 ? 2 * (idx - 18) : 10 + (idx - 23), cnt = idx < 23 ? 2 : 1;
+                            for (int k = 0; k < cnt; ++k) {
+                                const int rr = first + k;
                                 int slot = base_of(wbp, 0) + rr;
                                 slot -= slot >= 18 ? 18 : 0;
                                 x0_row(BH * pos + 13 + rr, slot);
                             }
-                        } else if (idx >= 6 && idx < 12) {
-                            // ... and long before that, their lines into L2 (one dword per 128 bytes by LDS-DMA into a scratch corner of
-                            // LDS, nobody reads it): the row DMAs then return in L2 time instead of sitting in this CU's memory queue
-                            // in front of the weight DMAs
-                            const int y0 = BH * pos + 13 + 2 * (idx - 6);
-                            const int row = lane / 24, c = (lane % 24) / 6, piece = lane % 6;
+                        } else if (tk >= 0 && !(NESR_STRIP_ABL & 32)) {
+                            // ... and long before that, their lines into L2: one dword per 128 bytes by LDS-DMA into a scratch corner of
+                            // LDS that nobody reads.  A load that goes out to HBM holds up whatever is queued behind it in this CU's
+                            // memory pipeline for its whole latency (measured: the weight DMAs of the next step land ~1500 cycles
+                            // late), so the touches go out in the steps that end with a layer's epilogue -- the one time the next
+                            // step's weights are not waited for -- and the row DMAs above then return in L2 time.
+                            const int t = lane + 64 * tk;
+                            const int row = t / 24, c = (t % 24) / 6, piece = t % 6;
                             const int x_lo = xs > 0 ? xs - 1 : 0, x_hi = xs + BW + 1 < w ? xs + BW + 1 : w;
                             const int seg = (x_hi - x_lo) * 32;
                             const int off = piece * 128 < seg - 4 ? piece * 128 : seg - 4;
-                            if (lane < 48 && y0 + row < h && !(NESR_STRIP_ABL & 32))
+                            const int y0 = BH * pos + 13;
+                            if (t < 288 && y0 + row < h)
                                 glds4_s(img_base + (size_t)y0 * a.W * 32,
                                         (unsigned)c * (unsigned)a.chunk_bytes + (unsigned)(row * a.W + x_lo) * 32u + (unsigned)off,
                                         __builtin_amdgcn_readfirstlane(lds0 + SCRO));
@@ -412,8 +415,12 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
     // one per MFMA gap with the weights of a column requested inside that column -- 6 to 12 MFMAs ahead -- is 14 % slower:
     // the LDS round trip under four waves' traffic is longer than that.)  No branch inside: a wave whose rows lie outside the
     // image multiplies too (its sums are masked in the epilogue; it would only wait at the barrier otherwise).
-    auto step_body = [&](auto Cc, const unsigned (&ba)[5], const unsigned (&nba)[5]) {
-        constexpr int CG = decltype(Cc)::value;
+    // LM (pixel-fragment loads of this step): 0 all; 1 columns 0 and 2 only, buffer 0 is left alone; 2 only the next step's first
+    // column.  conv5 runs the two cout groups of a chunk pair as steps (1, 2): the second one finds all three columns still in
+    // the registers.  (The next step's fragment addresses -- scalar work + five adds -- are computed before the step's barrier, not
+    // inside the MFMA stream: measured there, they cost the stream 350 cycles where they save 100 in front of the barrier.)
+    auto step_body = [&](auto Cc, auto Lc, const unsigned (&ba)[5], const unsigned (&nba)[5]) {
+        constexpr int CG = decltype(Cc)::value, LM = decltype(Lc)::value;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             int sl = aq + i + 1;
@@ -421,9 +428,9 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
-                if (i == 0) load_b1(1, k, ba, 0);
-                else if (i == 1) load_b1(2, k, ba, 2);
-                else load_b1(0, k, nba, 1);
+                if (i == 0) { if (LM != 2) load_b1(1, k, ba, 0); }
+                else if (i == 1) { if (LM != 2) load_b1(2, k, ba, 2); }
+                else if (LM != 1) load_b1(0, k, nba, 1);
             }
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                     SSTAMP(wv, sidx, 1);
-                    step_body(std::integral_constant<int, 0>{}, ba, nba);
+                    step_body(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ba, nba);
                     SSTAMP(wv, sidx, 2);
 #if NESR_STRIP_ABL & 256
                     ++sidx;
@@ -558,7 +565,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 SSTAMP(wv, sidx, 1);
-                step_body(std::integral_constant<int, 0>{}, ba, ba);       // the second cout group reads the same pixels
+                step_body(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, ba, ba);   // the second cout group finds these pixels in the registers
                 SSTAMP(wv, sidx, 2);
 #if NESR_STRIP_ABL & 256
                 ++sidx;
@@ -582,7 +589,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 SSTAMP(wv, sidx, 1);
-                step_body(std::integral_constant<int, 1>{}, ba, nba);
+                step_body(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, ba, nba);
                 SSTAMP(wv, sidx, 2);
 #if NESR_STRIP_ABL & 256
                 ++sidx;

@@ -97,7 +97,9 @@ class RealESRGANer:
         self.half = half
         self.tile_batch = 24  # upper bound on equal-shaped tiles per forward call (1 = upstream's serial loop)
         self.tile_streams = 3 # HIP streams (context replicas) the shape groups of one frame are spread over
-        self.ragged_tiles = False # bf16: tiles of different shapes in one batch per layer (see _run_tiles_ragged; measured: no faster)
+        self.ragged_tiles = None  # bf16: all tiles of a frame, whatever their shapes, in ragged batches (see _run_tiles_ragged).  None = when the
+                                  # model's dense blocks run as the LDS-resident strip kernel (rdb_bf16_strip.hip), whose schedule packs the
+                                  # strips of ALL tiles onto the compute units; with the per-layer kernels ragged batches measured no faster
         self.ragged_batch = 64    # tiles per ragged batch
         self.small_job_tiles = 12   # a call with at most this many tiles (a rank's share of a sharded frame) ...
         self.small_job_streams = 5  # ... is spread over this many streams, its batches split until every stream has one
@@ -232,8 +234,10 @@ class RealESRGANer:
             groups.setdefault((t[1] - t[0], t[3] - t[2]), []).append(t)
         order = sorted(groups.items(), key=lambda kv: -kv[0][0] * kv[0][1] * len(kv[1]))
         hip = isinstance(self.model, RRDBNet) and img.device.type == "cuda"
-        if hip and len(order) > 1 and img.shape[0] == 1 and self.ragged_tiles and self.model.compute_dtype == "bf16":
-            return self._run_tiles_ragged(img, tiles, sink)
+        if hip and img.shape[0] == 1 and self.model.compute_dtype == "bf16":
+            ragged = self.model.strip_kernel_active() if self.ragged_tiles is None else bool(self.ragged_tiles)
+            if ragged and (len(order) > 1 or self.ragged_tiles is None):
+                return self._run_tiles_ragged(img, tiles, sink, single_stream=self.ragged_tiles is None)
         # Batches of equal-shaped windows, one shape group per stream.  A small job (a rank's share of a sharded frame: five
         # tiles of an 8-way split 4K frame, often of one shape) is spread wider: every batch its own unit, the largest
         # halved until each of `small_job_streams` streams has one -- one stream would run 351 launches of a few hundred
@@ -293,7 +297,7 @@ class RealESRGANer:
         for s in streams[1:]:
             main.wait_stream(s)
 
-    def _run_tiles_ragged(self, img, tiles, sink):
+    def _run_tiles_ragged(self, img, tiles, sink, single_stream=False):
         """All windows of a frame, whatever their shapes, in `tile_streams` ragged batches that run side by side: every
         window lies in the top-left corner of an equal-sized slot and the kernels take each image's own size from the
         call (nesr_forward_ragged).  Against one batch per tile shape: the small edge-tile groups were latency-bound
@@ -304,7 +308,8 @@ class RealESRGANer:
         if not self.model.size_independent:
             self.model.size_independent = True
         cap = max(1, min(self.model.RAGGED_MAX, int(self.ragged_batch)))
-        nstreams = max(1, min(int(self.tile_streams), len(tiles)))
+        # (strip kernel: one batch after the other on one stream -- a persistent launch holds the whole device)
+        nstreams = 1 if single_stream else max(1, min(int(self.tile_streams), len(tiles)))
         # largest first, each to the least-loaded batch; a batch that is full opens another one on the same stream
         ts = sorted(tiles, key=lambda t: -(t[1] - t[0]) * (t[3] - t[2]))
         lanes = [[[]] for _ in range(nstreams)]

@@ -239,6 +239,13 @@ class RRDBNet(nn.Module):
         for h in handles:
             _lib.check(_lib.load().nesr_set_size_independent(h[0], 1 if on else 0), "nesr_set_size_independent")
 
+    def strip_kernel_active(self):
+        """True when bf16 dense blocks of a size-independent model run as the LDS-resident strip kernel (rdb_bf16_strip.hip;
+        NESR_STRIP=0 turns it off): the tiling wrapper then hands all tiles of a frame over as one ragged batch."""
+        import os
+        return (self.compute_dtype == "bf16" and self.size_independent and self.num_feat == 64 and self.num_grow_ch == 32
+                and self.num_block > 0 and os.environ.get("NESR_STRIP", "-1") != "0")
+
     # ------------------------------------------------------------------ forward
     def out_scale(self):
         """Output size / input size of forward(): 4 / unshuffle factor."""

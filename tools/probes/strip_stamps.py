@@ -40,5 +40,5 @@ print(f"position: {dt} memtime ticks in {dr} realtime ticks (100 MHz) = {dr / 10
 mf = sum(s[0][k][2] - s[0][k][1] for k in range(26)); wt = sum(s[0][k][1] - s[0][k][0] for k in range(26)); ep = sum(max(0, s[0][k][3] - s[0][k][2]) for k in range(26) if s[0][k][3] > s[0][k][2])
 print(f"sums: mfma {mf} wait {wt} epilogue {ep} other {dt - mf - wt - ep}")
 print("per-wave barrier arrival of steps 6..9 (relative to wave 0's):")
-for k in range(6, 10):
+for k in (3, 6, 10, 14, 15, 19, 20, 21):
     print(k, [s[w][k][0] - s[0][k][0] for w in range(NW)], "release", [s[w][k][1 if w < 4 else 2] - s[0][k][0] for w in range(NW)])
