@@ -173,6 +173,23 @@ int nesr_band_rows(nesr_ctx* ctx, int buffer, int row0, int nrows, void* staging
 int nesr_set_concurrent(nesr_ctx* ctx, int concurrent);
 
 /*
+ * The dense blocks of small f32 frames (rdb_f16x2_kernel) and of bf16 tile batches (rdb_bf16_strip_kernel) run as PERSISTENT
+ * launches whose workgroups wait for one another; they need every workgroup resident, i.e. the device to themselves.  Inside a
+ * process such launches of different contexts / streams are serialised per device (an event wait, no host blocking).  Against
+ * another process nothing can order them: every wait is bounded by wall clock (200 ms; NESR_FUSED_TIMEOUT_MS), a workgroup
+ * that gives up raises an abort word that ends all other waits of that forward at once, nesr_check_range / nesr_check_status
+ * then return NESR_ERR_HIP for it, and the context switches to per-layer launches for good (f32: the same values bit for bit;
+ * bf16: the per-layer kernels' values) -- re-run the frame.  nesr_set_fused(ctx, 0 | 1) makes that choice by hand;
+ * nesr_fused_state returns bit 0 = persistent launches enabled, bits 1.. = forwards that gave up so far.
+ * nesr_debug_fault is a TEST HOOK: the next persistent launch leaves out its last `drop_workgroups` workgroups (their
+ * neighbours' waits must end in the abort word within the time limit).
+ * Stands behind the same reference calls as nesr_forward (nesr/nesr.py:887-891, standalone/direct_esrgan.py:148).
+ */
+int nesr_set_fused(nesr_ctx* ctx, int on);
+int nesr_fused_state(const nesr_ctx* ctx);
+int nesr_debug_fault(nesr_ctx* ctx, int drop_workgroups);
+
+/*
  * Timing hook for bench.py's roofline leg: when enabled, forward() brackets the dominant kernel
  * family (the dense-block 3x3 convs) with hipEvents on the caller's stream; nesr_kernel_time_ms
  * returns the accumulated elapsed ms and launch count since the last call (synchronises those
@@ -186,8 +203,8 @@ int nesr_kernel_time_ms(nesr_ctx* ctx, double* total_ms, int64_t* launches, doub
  * form's range flag, see nesr_check_range). */
 int nesr_check_status(nesr_ctx* ctx);
 
-/* Range check of the forwards enqueued so far on `hip_stream` (NESR_DTYPE_F32_SPLIT; NESR_OK at once for the
- * other dtypes): waits for that stream only, returns NESR_ERR_RANGE if an input or activation did not fit the
+/* Range / abort check of the forwards enqueued so far on `hip_stream` (NESR_DTYPE_F32_SPLIT, and contexts whose dense blocks
+ * ran as persistent launches; NESR_OK at once otherwise): waits for that stream only, returns NESR_ERR_RANGE if an input or activation did not fit the
  * (hi, lo) pair, and clears the flag.  Where the reference would hand back NaN/Inf pixels
  * (`model(img)` on diverged data, nesr/nesr.py:891) this path hands back NaN (float output) plus this error; the
  * Python wrappers call it after every device-to-host copy. */

@@ -40,6 +40,9 @@ SIGNATURES = {
     "nesr_band_row_bytes": (_c.c_size_t, [_c.c_void_p]),
     "nesr_band_rows": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p]),
     "nesr_set_concurrent": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "nesr_set_fused": (_c.c_int, [_c.c_void_p, _c.c_int]),
+    "nesr_fused_state": (_c.c_int, [_c.c_void_p]),
+    "nesr_debug_fault": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "nesr_set_kernel_timing": (_c.c_int, [_c.c_void_p, _c.c_int]),
     "nesr_kernel_time_ms": (_c.c_int, [_c.c_void_p, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64), _c.POINTER(_c.c_double)]),
     "nesr_check_status": (_c.c_int, [_c.c_void_p]),

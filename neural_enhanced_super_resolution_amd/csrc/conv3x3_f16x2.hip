@@ -534,6 +534,7 @@ struct RdbArgs {
     unsigned epoch;          // progress == epoch + j  <=>  x_j of this launch is visible
     unsigned* abort_flag;
     unsigned* status;        // sticky range word (ConvArgs::status)
+    unsigned long long timeout_ticks;   // s_memrealtime ticks (100 MHz) a neighbour wait may take
 };
 
 __device__ __forceinline__ void glds16_s_sc1(const char* sbase, unsigned voff, unsigned lds_dst) {
@@ -691,6 +692,9 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
             for (int j = 0; j < W_ROUNDS; ++j) kdma += (wave * 64 + THREADS * j) < W_ITEMS ? 1 : 0;
         }
         unsigned seen = 0;     // layers of this launch known to be published by all nine tiles
+        // an abort word raised earlier in this forward (or by another workgroup): nothing is waited for any more -- the forward's
+        // output is invalid either way and the host turns the word into NESR_ERR_HIP (nesr_check_range)
+        bool gave_up = __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
         // DMAs of one step: weight slab of (layer l, cout group cg, chunk c), then input chunk c -- after the nine tiles
         // have published the layer that produced it (chunks 4.. hold x1..: chunk c belongs to x_((c-4)/2+1)).
         // Exactly kdma wave instructions.
@@ -704,14 +708,24 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
                 if (k < W_ITEMS && !(NESR_RDB_ABL & 64)) glds16_s(wsrc, (unsigned)k * 16u, __builtin_amdgcn_readfirstlane(dst));
             }
             const unsigned need = c < 4 ? 0u : (unsigned)((c - 4) >> 1) + 1u;
-            if (need > seen && !(NESR_RDB_ABL & 1)) {
+            if (need > seen && !gave_up && !(NESR_RDB_ABL & 1)) {
                 const unsigned target = a.epoch + need;
+                unsigned long long t0 = 0;
                 for (unsigned it = 0;; ++it) {
                     const unsigned v = watch ? __hip_atomic_load(watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
                     if (__builtin_amdgcn_ballot_w64((int)(v - target) < 0) == 0ull) break;
-                    if (it > (1u << 22)) {     // ~1 s: a neighbour never arrived (workgroups not co-resident?)
-                        if (lane == 0) __hip_atomic_store(a.abort_flag, 1u | ((unsigned)c << 8) | ((unsigned)tile << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break;
+                    if ((it & 63u) == 0u) {
+                        // bounded by wall clock: a neighbour that never arrives (workgroups not co-resident: another process's
+                        // persistent kernel on the device) ends in an abort word within timeout_ticks, and once the word is up --
+                        // here or in any other workgroup -- every later wait of the launch and of the forward is skipped
+                        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+                        if (it == 0) t0 = now;
+                        const unsigned ab = __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (ab != 0u || now - t0 > a.timeout_ticks) {
+                            if (ab == 0u && lane == 0) __hip_atomic_store(a.abort_flag, 1u | ((unsigned)c << 8) | ((unsigned)tile << 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            gave_up = true;
+                            break;
+                        }
                     }
                     __builtin_amdgcn_s_sleep(4);
                 }
@@ -1166,7 +1180,20 @@ hipError_t launch_rdb_f16x2(const RdbLaunch& r, hipStream_t s) {
     for (int i = 0; i < 5; ++i) { a.w[i] = r.w[i]; a.bias[i] = r.bias[i]; }
     a.n = r.n; a.h = r.h; a.w_ = r.w_;
     a.progress = r.progress; a.epoch = r.epoch; a.abort_flag = r.abort_flag; a.status = r.status;
-    const int total = rdb_f16x2_tiles(r.n, r.h, r.w_);
+    a.timeout_ticks = r.timeout_ticks ? r.timeout_ticks : 20000000ull;
+    int total = rdb_f16x2_tiles(r.n, r.h, r.w_);
+    if (total <= 0) return hipSuccess;
+    // every tile needs its own RESIDENT workgroup: what the device admits of this kernel (registers, LDS) times its compute units
+    static int resident = -1;
+    if (resident < 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rdb_f16x2_kernel, 64 * (MW + DW), shm) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return hipErrorUnknown;
+        resident = per_cu * cus;
+    }
+    if (total > resident) return hipErrorLaunchOutOfResources;
+    total -= r.debug_drop;       // test hook (nesr_debug_fault): the last workgroups never start, their neighbours' waits must end in the abort word
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(rdb_f16x2_kernel, dim3((unsigned)total), dim3(64 * (MW + DW)), shm, s, a);
     return hipGetLastError();

@@ -95,7 +95,10 @@ struct nesr_ctx {
     int strip_mode = -1;             // NESR_STRIP: -1 auto (size-independent contexts, or batches that fill the device), 0 never, 1 wherever it applies
     unsigned strip_epoch = 0;
     bool strip_used = false;         // a strip launch went out since the last status check
-    unsigned long long strip_timeout_ticks = 20000000ull;   // 200 ms of s_memrealtime
+    unsigned long long strip_timeout_ticks = 20000000ull;   // 200 ms of s_memrealtime: what an inter-workgroup wait of a persistent kernel may take
+    int rdb_mode_init = -1, strip_mode_init = -1;
+    int debug_drop = 0;              // nesr_debug_fault: workgroups the next persistent launch leaves out
+    int fused_aborts = 0;            // persistent launches that gave up (the context runs per-layer launches from then on)
     struct StripPlan {
         std::vector<int> key;        // N, H, W, then (h, w) of every image
         void* d_items = nullptr; int* d_first = nullptr; char* d_xch = nullptr;
@@ -393,7 +396,14 @@ int fw_rdb(nesr_ctx* c, const FwState& F, int b, int r, hipStream_t s, int phase
             L.epoch = c->strip_epoch;
             L.abort_flag = c->d_status + 2;
             L.timeout_ticks = c->strip_timeout_ticks;
-            HIP_TRY(launch_rdb_bf16_strip(L, s));
+            L.debug_drop = c->debug_drop;
+            c->debug_drop = 0;
+            const hipError_t le = launch_rdb_bf16_strip(L, s);
+            if (le == hipErrorLaunchOutOfResources) {
+                c->strip_mode = 0;      // the device does not admit the kernel's workgroups (LDS / registers): per-layer launches
+                return fw_rdb(c, F, b, r, s, phase, top, bottom, edge);
+            }
+            HIP_TRY(le);
             c->strip_used = true;
             if (c->timing) {
                 double px_real = 0.0;      // ragged batches: the images' own pixels
@@ -429,7 +439,16 @@ int fw_rdb(nesr_ctx* c, const FwState& F, int b, int r, hipStream_t s, int phase
             L.epoch = c->rdb_epoch;
             L.abort_flag = c->d_status + 1;
             L.status = c->d_status;
-            HIP_TRY(launch_rdb_f16x2(L, s));
+            L.timeout_ticks = c->strip_timeout_ticks;
+            L.debug_drop = c->debug_drop;
+            c->debug_drop = 0;
+            const hipError_t le = launch_rdb_f16x2(L, s);
+            if (le == hipErrorLaunchOutOfResources) {
+                c->rdb_mode = 0;        // fewer resident workgroups than tiles: per-layer launches (the same bits)
+                return fw_rdb(c, F, b, r, s, phase, top, bottom, edge);
+            }
+            HIP_TRY(le);
+            c->strip_used = true;       // (the abort word of either persistent kernel is looked at by nesr_check_range)
             if (c->timing) c->timed_launches += 1;
             return NESR_OK;
         }
@@ -637,7 +656,9 @@ int nesr_create(nesr_ctx** out, int device_id, int conv_first_in_ch, int unshuff
     if (const char* e = getenv("NESR_TRUNK")) c->trunk_mode = e[0] == 'l' ? 1 : (e[0] == 'p' ? 2 : 0);
     if (const char* e = getenv("NESR_RDB_FUSE")) c->rdb_mode = atoi(e);
     if (const char* e = getenv("NESR_STRIP")) c->strip_mode = atoi(e);
-    if (const char* e = getenv("NESR_STRIP_TIMEOUT_MS")) c->strip_timeout_ticks = (unsigned long long)atoll(e) * 100000ull;
+    c->rdb_mode_init = c->rdb_mode;
+    c->strip_mode_init = c->strip_mode;
+    if (const char* e = getenv("NESR_FUSED_TIMEOUT_MS")) c->strip_timeout_ticks = (unsigned long long)atoll(e) * 100000ull;
     (void)hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device_id);
     auto add = [&](const std::string& name, int cin, int cout) {
         Layer L;
@@ -925,6 +946,25 @@ int nesr_set_concurrent(nesr_ctx* c, int concurrent) {
     return NESR_OK;
 }
 
+int nesr_set_fused(nesr_ctx* c, int on) {
+    if (!c) return fail(NESR_ERR_ARG, "null ctx");
+    c->rdb_mode = on ? c->rdb_mode_init : 0;          // on: what the context was created with (NESR_RDB_FUSE / NESR_STRIP, default auto)
+    c->strip_mode = on ? c->strip_mode_init : 0;
+    return NESR_OK;
+}
+
+int nesr_fused_state(const nesr_ctx* c) {
+    if (!c) return 0;
+    const int on = c->dtype == NESR_DTYPE_BF16 ? c->strip_mode != 0 : (c->dtype == NESR_DTYPE_F32_SPLIT && c->rdb_mode != 0);
+    return (on ? 1 : 0) | (c->fused_aborts << 1);
+}
+
+int nesr_debug_fault(nesr_ctx* c, int drop_workgroups) {
+    if (!c) return fail(NESR_ERR_ARG, "null ctx");
+    c->debug_drop = drop_workgroups > 0 ? drop_workgroups : 0;
+    return NESR_OK;
+}
+
 int nesr_set_kernel_timing(nesr_ctx* c, int enable) {
     if (!c) return fail(NESR_ERR_ARG, "null ctx");
     c->timing = enable != 0;
@@ -976,10 +1016,12 @@ int nesr_check_range(nesr_ctx* c, void* stream) {
         HIP_TRY(hipMemsetAsync(c->d_status + 2, 0, 4, s));
         HIP_TRY(hipStreamSynchronize(s));
         c->h_status[2] = 0;
+        c->strip_mode = 0;       // this context runs per-layer launches from now on (valid values; not the strip kernel's bits)
+        ++c->fused_aborts;
         return fail(NESR_ERR_HIP, "the LDS-resident dense-block kernel gave up waiting for a neighbouring strip's edge column (workgroup " +
                                   std::to_string(code >> 16) + ", layer " + std::to_string((code >> 8) & 255u) +
                                   ": its workgroups were not all resident -- another process's persistent kernel shares the device?); the "
-                                  "output of that forward is invalid. NESR_STRIP=0 selects per-layer launches");
+                                  "output of that forward is invalid; this context uses per-layer launches from now on (re-run the frame)");
     }
     if (c->dtype != NESR_DTYPE_F32_SPLIT) return NESR_OK;
     if (c->h_status[1]) {
@@ -987,10 +1029,12 @@ int nesr_check_range(nesr_ctx* c, void* stream) {
         HIP_TRY(hipMemsetAsync(c->d_status, 0, 8, s));
         HIP_TRY(hipStreamSynchronize(s));
         c->h_status[0] = c->h_status[1] = 0;
+        c->rdb_mode = 0;         // per-layer launches from now on: the same values bit for bit, no inter-workgroup waits
+        ++c->fused_aborts;
         return fail(NESR_ERR_HIP, "the fused dense-block kernel gave up waiting for a neighbouring tile's progress word (tile " +
                                   std::to_string(code >> 16) + ", input chunk " + std::to_string((code >> 8) & 255u) +
                                   ": its workgroups were not all resident -- another persistent kernel shares the device?); the "
-                                  "output of that forward is invalid. NESR_RDB_FUSE=0 selects per-layer launches");
+                                  "output of that forward is invalid; this context uses per-layer launches (the same bits) from now on: re-run the frame");
     }
     if (*c->h_status) {
         HIP_TRY(hipMemsetAsync(c->d_status, 0, 4, s));   // reported once; the next forward starts clean

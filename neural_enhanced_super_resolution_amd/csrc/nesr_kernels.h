@@ -132,6 +132,8 @@ struct RdbLaunch {
     unsigned epoch;           // strictly increasing by >= 8 per launch
     unsigned* abort_flag;
     unsigned* status;
+    unsigned long long timeout_ticks;   // 100 MHz ticks a neighbour wait may take (0: 200 ms)
+    int debug_drop;           // test hook: this many workgroups of the launch never start
 };
 int rdb_f16x2_tiles(int n, int h, int w);
 hipError_t launch_rdb_f16x2(const RdbLaunch& r, hipStream_t s);
@@ -161,6 +163,7 @@ struct StripLaunch {
     unsigned epoch;                               // strictly increasing by >= 2048 per launch
     unsigned* abort_flag;
     unsigned long long timeout_ticks;
+    int debug_drop;                               // test hook: this many workgroups of the launch never start
 };
 hipError_t launch_rdb_bf16_strip(const StripLaunch& r, hipStream_t s);
 

@@ -773,7 +773,18 @@ hipError_t launch_rdb_bf16_strip(const StripLaunch& r, hipStream_t s) {
     a.epoch = r.epoch;
     a.abort_flag = r.abort_flag;
     a.timeout_ticks = r.timeout_ticks;
-    hipLaunchKernelGGL(rdb_bf16_strip_kernel, dim3((unsigned)r.grid), dim3(64 * (MW + DW)), LDSB, s, a);
+    static int resident = -1;      // one workgroup per CU (LDS): the schedule's grid is at most the compute-unit count
+    if (resident < 0) {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rdb_bf16_strip_kernel, 64 * (MW + DW), LDSB) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            return hipErrorUnknown;
+        resident = per_cu * cus;
+    }
+    if (r.grid > resident) return hipErrorLaunchOutOfResources;
+    const int grid = r.grid - r.debug_drop;     // test hook (nesr_debug_fault): the last workgroups never start
+    if (grid <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rdb_bf16_strip_kernel, dim3((unsigned)grid), dim3(64 * (MW + DW)), LDSB, s, a);
     return hipGetLastError();
 }
 

@@ -514,7 +514,23 @@ class RealESRGANer:
 
     @torch.no_grad()
     def enhance(self, img, outscale=None, alpha_upsampler="realesrgan"):
-        """img: HWC uint8/uint16 BGR | BGRA | gray ndarray -> (ndarray of the same kind, upscaled; img_mode)."""
+        """img: HWC uint8/uint16 BGR | BGRA | gray ndarray -> (ndarray of the same kind, upscaled; img_mode).
+
+        A forward whose persistent dense-block launch gave up waiting (another process's kernels kept its workgroups off the
+        device: NesrHipError from the status check, never a silently wrong image) is evaluated once more: the context has
+        switched to per-layer launches by then (include/nesr_hip.h, nesr_set_fused)."""
+        from ._lib import NesrHipError, NesrRangeError
+        try:
+            return self._enhance_once(img, outscale, alpha_upsampler)
+        except NesrRangeError:
+            raise
+        except NesrHipError as e:
+            if "gave up waiting" not in str(e):
+                raise
+            warnings.warn(f"{e}; evaluating the frame again with per-layer launches")
+            return self._enhance_once(img, outscale, alpha_upsampler)
+
+    def _enhance_once(self, img, outscale=None, alpha_upsampler="realesrgan"):
         h_input, w_input = img.shape[0:2]
         plain_alpha = alpha_upsampler != "realesrgan" and img.ndim == 3 and img.shape[2] == 4
 

@@ -449,6 +449,28 @@ class RRDBNet(nn.Module):
         with torch.cuda.device(dev):
             _lib.check(lib.nesr_band_rows(ctx, int(buffer), int(row0), rows.numel() // rb, ctypes.c_void_p(rows.data_ptr()), 1, stream), "nesr_band_rows")
 
+    def _handles(self):
+        return ([self._ctx] if self._ctx is not None else []) + list(self._extra.values())
+
+    def set_fused(self, on: bool):
+        """Persistent (fused) dense-block launches on / off for every context of this model (include/nesr_hip.h: nesr_set_fused).
+        They switch themselves off after a forward that gave up waiting (NesrHipError at check_range / check_status)."""
+        for h in self._handles():
+            _lib.check(_lib.load().nesr_set_fused(h[0], 1 if on else 0), "nesr_set_fused")
+
+    def fused_state(self, slot=0):
+        """(persistent launches enabled, forwards that gave up so far) of a context."""
+        h = self._ctx if slot == 0 else self._extra.get(slot)
+        if h is None:
+            return False, 0
+        v = int(_lib.load().nesr_fused_state(h[0]))
+        return bool(v & 1), v >> 1
+
+    def debug_fault(self, drop_workgroups=1, slot=0):
+        """TEST HOOK: the next persistent launch of the context leaves out its last workgroups (nesr_debug_fault)."""
+        h = self._ctx if slot == 0 else self._extra.get(slot)
+        _lib.check(_lib.load().nesr_debug_fault(h[0], int(drop_workgroups)), "nesr_debug_fault")
+
     def set_concurrent(self, concurrent: bool):
         """Hint for kernel selection: forwards of this model's contexts run beside each other on several streams
         (set automatically when a context replica is created; clear it to time one forward alone)."""
@@ -476,7 +498,7 @@ class RRDBNet(nn.Module):
                   [self._ctx if slot == 0 else self._extra.get(slot)]
         lib = _lib.load()
         for h in handles:
-            if h is None or h[2] != _lib.DTYPE_F32_SPLIT:
+            if h is None or h[2] not in (_lib.DTYPE_F32_SPLIT, _lib.DTYPE_BF16):     # the forms with a range word or persistent launches
                 continue
             dev = torch.device("cuda", h[1])
             with torch.cuda.device(dev):
