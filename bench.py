@@ -10,14 +10,16 @@ N > 1 may be started plainly (this process then spawns `python -m torch.distribu
 Workload (BASELINE.json configs[1], "c2"): synthetic 512x512 -> 1024x1024 RealESRGAN_x2plus, fp32, single tile,
 input already resident in HBM as the NCHW float tensor RealESRGANer.process() hands to ``self.model`` (the drop-in
 boundary).  Frames are independent units, so N GPUs run their own frames with no data-path
-collective ("scaling": "weak").  `value` is THROUGHPUT with `frames_in_flight_per_gpu` (default 4) independent frames
-per GPU, each on its own HIP stream; the reference's batch-1 call is the `single_frame` object of the same line, and
-the `roofline` object is measured on that single-frame region (the kernel by itself).
+collective ("scaling": "weak").  `value` is one frame at a time per GPU -- the reference's batch-1 call
+(standalone/direct_esrgan.py:148), whose dense blocks run as rdb_f16x2_kernel -- and the `roofline` object describes that same
+timed region and kernel.  `frames_in_flight` is the extra: THROUGHPUT with 4 independent frames per GPU, each on its own HIP stream
+and context replica (per-layer kernels: the persistent kernel wants the device to itself), timed right after.
 
 The line also carries
   strict_f32   the same frame on the f32 matrix cores (Winograd F(2x2,3x3) and direct implicit GEMM): ms, MP/s,
                fraction of the 157.3 TFLOP/s f32 MFMA peak, max abs vs the CPU oracle -- the default `dtype` is f32 in /
                out / accumulate with operands carried as f16 (hi, lo) pairs, so the strict forms are timed beside it;
+  c4_stream    BASELINE.json configs[3] (1920x1080 -> 7680x4320 RealESRGAN_x4plus, bf16, tile 512/10), one frame per GPU;
   c3 / c3_stream   BASELINE.json configs[2] (3840x2160 -> 7680x4320, bf16, RealESRGANer(tile=512, tile_pad=10)): one
                frame for the whole job, tiles sharded over the ranks (sharded.py: RCCL point-to-point overlap rows,
                gather on rank 0), and one independent frame per GPU; frames/s of the whole job;
@@ -209,8 +211,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the strict_f32 / c3 / c3_stream objects of the default c2 line")
     ap.add_argument("--inflight", type=int, default=None,
-                    help="frames in flight per GPU for the single-tile workloads (each on its own HIP stream and context "
-                         "replica); default 4 for c2 / c2-bf16 (2: -5 %%, 1: -20 %%, 6-8: no more), 1 otherwise")
+                    help="frames in flight per GPU for the `frames_in_flight` extra of the single-tile workloads (each on its own HIP "
+                         "stream and context replica); default 4 for c2 / c2-bf16, 0 = skip; `value` is always one frame at a time")
     ap.add_argument("--f32-algo", default=None, choices=["split", "winograd", "direct"],
                     help="conv algorithm of the fp32 workloads (default split: f16 hi+lo operand pairs)")
     ap.add_argument("--filters", action="store_true", help="c5: also run the reference's cv2 pre / post filters (imgproc.py: NL-means + CLAHE, adaptive unsharp)")
@@ -301,24 +303,10 @@ def main():
     # replica -- a 512x512 frame's layers are one-round launches of 256-512 workgroups (all in their prologue, then
     # all in their epilogue, 1.3 us between dependent kernels), so a second frame's kernels fill the gaps and the
     # idle half of the LDS / wave slots (tools/probes/concurrent_frames.py, tools/probes/launch_floor.hip)
-    inflight = args.inflight if args.inflight else (4 if (wl["tile"] == 0 and not wl.get("banded")) else 1)
-    if wl["tile"] > 0 or wl.get("banded"):
-        inflight = 1
-    xs, streams = [x], [torch.cuda.current_stream(dev)]
-    for i in range(1, inflight):
-        up.pre_process(np.ascontiguousarray(synthetic_frame(wl["h"], wl["w"], seed=1000 * i + rank)[:, :, ::-1].astype(np.float32) / 255.0))
-        xs.append(up.img)
-        streams.append(torch.cuda.Stream(dev))
-    for st in streams[1:]:
-        st.wait_stream(streams[0])      # xs[i] were produced on the main stream
+    extra_inflight = (4 if args.inflight is None else args.inflight) if (wl["tile"] == 0 and not wl.get("banded")) else 0
+    inflight = 1
 
     def step():
-        if inflight > 1:
-            ys = []
-            for i in range(inflight):
-                with torch.cuda.stream(streams[i]):
-                    ys.append(model(xs[i], slot=i))
-            return ys[0]
         if banded_frame:
             return banded.enhance_banded(up, band, (wl["h"], wl["w"]))
         if sharded_frame:
@@ -333,36 +321,47 @@ def main():
         step()
     torch.cuda.synchronize(dev)
     log("warmup done")
-    # HIP-event brackets around the dense-block convs, on the launch stream.  With several frames in flight the
-    # brackets of the streams overlap, so the roofline leg is measured on a second timed region below (one frame,
-    # one stream: the kernel by itself, which is also what the committed rocprofv3 summary shows)
-    model.set_kernel_timing(dev, inflight == 1)
+    # HIP-event brackets around the dense blocks, on the launch stream, over the timed region itself
+    model.set_kernel_timing(dev, True)
     model.kernel_time()
     elapsed = timed(step, args.steps, 0)
     k_ms, k_launches, k_flops = model.kernel_time()
     model.set_kernel_timing(dev, False)
     model.check_status()
-    single = None
-    if inflight > 1:
-        model.set_concurrent(False)          # one frame alone: the device is this context's
-        model.set_kernel_timing(dev, True)
-        model.kernel_time()
+    flight = None
+    if extra_inflight > 1:
+        # the throughput extra: `extra_inflight` independent frames per step, each on its own stream with its own context replica --
+        # a 512x512 frame's per-layer launches are one-round grids of 256-512 workgroups (all in their prologue, then all in their
+        # epilogue, 1.3 us between dependent kernels), so a second frame's kernels fill the gaps (tools/probes/concurrent_frames.py)
+        xs, streams = [x], [torch.cuda.current_stream(dev)]
+        for i in range(1, extra_inflight):
+            up.pre_process(np.ascontiguousarray(synthetic_frame(wl["h"], wl["w"], seed=1000 * i + rank)[:, :, ::-1].astype(np.float32) / 255.0))
+            xs.append(up.img)
+            streams.append(torch.cuda.Stream(dev))
+        for st in streams[1:]:
+            st.wait_stream(streams[0])      # xs[i] were produced on the main stream
+
+        def step_flight():
+            ys = []
+            for i in range(extra_inflight):
+                with torch.cuda.stream(streams[i]):
+                    ys.append(model(xs[i], slot=i))
+            return ys[0]
+
+        for _ in range(2):
+            step_flight()
         torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            model(x)
-        torch.cuda.synchronize(dev)
-        single = (time.perf_counter() - t1) / args.steps
-        k_ms, k_launches, k_flops = model.kernel_time()
-        model.set_kernel_timing(dev, False)
-        model.set_concurrent(True)
+        flight = timed(step_flight, args.steps, 0)
+        model.check_status()
+        model.set_concurrent(False)          # back to one frame alone: the device is this context's
+        del xs
 
     out_mp = wl["h"] * netscale * wl["w"] * netscale / 1e6
-    frames_per_step = 1 if (sharded_frame or banded_frame) else world * inflight
+    frames_per_step = 1 if (sharded_frame or banded_frame) else world
     value = frames_per_step * args.steps * out_mp / elapsed
     frame_flops = net.forward_flops(1, wl["h"], wl["w"])
     name = "RealESRGAN_x2plus x2" if scale == 2 else "RealESRGAN_x4plus x4"
-    multi = f", {inflight} independent frames in flight per GPU (single-frame latency: `single_frame`)" if inflight > 1 else ""
+    multi = ""
 
     result = {
         "metric": f"output megapixels/sec, {name} upscale{multi}",
@@ -380,7 +379,8 @@ def main():
         "frames_per_s": round(frames_per_step * args.steps / elapsed, 4),
         "tflops_whole_net": round(frames_per_step * args.steps * frame_flops / elapsed / 1e12, 2),
     }
-    multi_stream = wl["tile"] > 0 and getattr(up, "tile_streams", 1) > 1
+    strip = dtype == "bf16" and wl["tile"] > 0 and model.strip_kernel_active()
+    multi_stream = wl["tile"] > 0 and getattr(up, "tile_streams", 1) > 1 and not strip
     if k_ms > 0:
         # concurrent streams: per-stream event brackets overlap, so divide the trunk FLOPs by the wall
         # time of the timed region instead (includes the non-trunk kernels: a lower bound)
@@ -398,17 +398,18 @@ def main():
                               "frac": round(achieved / peak, 4), "traffic": pmc_traffic(tkey),
                               "algorithm": algo["algorithm"] if algo else "direct implicit GEMM, v_mfma_f32_32x32x16_bf16",
                               "executed_frac": round(achieved * per_alg / peak, 4),
-                              "kernel": ("rdb_f16x2_kernel (conv1..conv5 of a dense block in one launch: 69 launches = the 345 dense-block convs of a frame)"
+                              "kernel": ("rdb_bf16_strip_kernel (conv1..conv5 of a dense block of ALL tiles of the frame in one persistent launch, working set in LDS: 69 launches per frame)"
+                                         if strip else
+                                         "rdb_f16x2_kernel (conv1..conv5 of a dense block in one launch: 69 launches = the 345 dense-block convs of a frame)"
                                          if (algo is F32_ALGOS["split"] and k_launches and k_flops / k_launches > 2e10) else
                                          "conv3x3_f16x2_kernel / conv3x3_wino_f32_kernel / conv3x3_mfma_kernel / conv3x3_bf16_xl_kernel (the 345 dense-block convs per frame)"),
                               "avg_launch_us": round(1e3 * k_ms / max(k_launches, 1), 2), "launches": int(k_launches)}
-        if inflight > 1:
-            result["roofline"]["measured_on"] = (f"a second timed region of {args.steps} single-frame forwards on one stream "
-                                                 "(the kernel by itself; `value` is the throughput with frames in flight)")
-    if single is not None:
-        # one frame alone, same process, same device: the latency figure (and what `value` is with --inflight 1)
-        result["single_frame"] = {"ms": round(1e3 * single, 3), "mp_s": round(out_mp / single, 3),
-                                  "tflops_whole_net": round(frame_flops / single / 1e12, 2)}
+        result["roofline"]["measured_on"] = "the timed region of `value` (HIP events on the launch stream around the dense blocks of every frame)"
+    if flight is not None:
+        result["frames_in_flight"] = {"frames_per_gpu": extra_inflight, "mp_s": round(world * extra_inflight * args.steps * out_mp / flight, 3),
+                                      "ms_per_step": round(1e3 * flight / args.steps, 3),
+                                      "note": "throughput with independent frames on their own HIP streams and context replicas (per-layer kernels); "
+                                              "not the headline: `value` and `roofline` are one frame at a time"}
 
     extras = args.workload == "c2" and not args.no_extras
     yref = xc = None
@@ -440,7 +441,7 @@ def main():
         if rank == 0:
             log("strict f32 forms")
             result["strict_f32"] = strict_f32(args, sd, x, xc, yref, dev, out_mp, frame_flops)
-        del xs, up, model, net
+        del up, model, net
         torch.cuda.empty_cache()
         log("c3 objects")
         # The 4K objects are extras of this line: whatever happens in them -- an exception on this rank, or (N > 1) a rank
@@ -448,14 +449,20 @@ def main():
         # printed, with the failure named where the object would have been.
         import threading
         state = {"printed": False}
-        limit = 240.0
+        plock = threading.Lock()
+        limit = 300.0
 
         def give_up():
-            if rank == 0 and not state["printed"]:
-                result.setdefault("c3", {"error": f"no result after {limit:.0f} s: a rank did not come back from the sharded 4K frame "
-                                                   "(RCCL point-to-point exchange / gather)"})
-                print(json.dumps(result), flush=True)
-            os._exit(0 if rank == 0 else 3)
+            # the headline is printed (once) with the hang named in it, and EVERY rank leaves with a failure status: a hung
+            # exchange must not read as success
+            if rank == 0:
+                with plock:
+                    if not state["printed"]:
+                        state["printed"] = True
+                        result.setdefault("c3", {"error": f"no result after {limit:.0f} s: a rank did not come back from the sharded 4K frame "
+                                                           "(RCCL point-to-point exchange / gather)"})
+                        print(json.dumps(result), flush=True)
+            os._exit(4 if rank == 0 else 3)
 
         watchdog = threading.Timer(limit, give_up)
         watchdog.daemon = True
@@ -469,9 +476,13 @@ def main():
     else:
         watchdog = None
     if rank == 0:
-        print(json.dumps(result), flush=True)
         if extras:
-            state["printed"] = True
+            with plock:
+                if not state["printed"]:
+                    state["printed"] = True
+                    print(json.dumps(result), flush=True)
+        else:
+            print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         if watchdog is not None:
@@ -513,35 +524,76 @@ def strict_f32(args, sd, x, xc, yref, dev, out_mp, frame_flops):
     return out
 
 
-def c3_objects(args, dev, rank, world, timed):
-    """BASELINE.json configs[2] beside the headline: one 2160p frame sharded over the ranks (strong scaling) and one
-    independent 2160p frame per GPU (weak scaling), bf16, RealESRGANer(tile=512, tile_pad=10)."""
+def stream_object(args, dev, rank, world, timed, scale, H, W, key, name):
+    """One independent frame per GPU through RealESRGANer(tile=512, tile_pad=10), bf16, device-resident input: frames/s of the
+    whole job and a `roofline` object for its dominant kernel (the dense blocks), HIP events around them on the launch stream
+    over the timed region.  Returns (RealESRGANer, dict)."""
     import numpy as np
-    import torch
-    from neural_enhanced_super_resolution_amd import RRDBNet, RealESRGANer, sharded
+    from neural_enhanced_super_resolution_amd import RRDBNet, RealESRGANer
     from neural_enhanced_super_resolution_amd.synth import synthetic_frame, synthetic_state_dict
-    H, W = 2160, 3840
-    sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=2)
-    up = RealESRGANer(scale=2, model_path={"params_ema": sd}, model=RRDBNet(3, 3, scale=2, compute_dtype="bf16"), tile=512,
+    netscale = {2: 2, 1: 1}.get(scale, 4)
+    sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=scale)
+    up = RealESRGANer(scale=netscale, model_path={"params_ema": sd}, model=RRDBNet(3, 3, scale=scale, compute_dtype="bf16"), tile=512,
                       tile_pad=10, pre_pad=0, half=False, device=dev)
+    steps, warm = max(2, min(args.steps, 6)), 2
+    flops = up.model.forward_flops(1, H, W)
+    mine = synthetic_frame(H, W, seed=rank)
+    up.pre_process(np.ascontiguousarray(mine[:, :, ::-1].astype(np.float32) / 255.0))
+    for _ in range(warm):
+        up.tile_process()
+    up.model.set_kernel_timing(dev, True)
+    up.model.kernel_time()
+    el = timed(up.tile_process, steps, 0)
+    k_ms, k_n, k_fl = up.model.kernel_time()
+    up.model.set_kernel_timing(dev, False)
+    up.model.check_status()
+    out_mp = netscale * netscale * H * W / 1e6
+    strip = up.model.strip_kernel_active()
+    obj = {"workload": f"one independent {W}x{H}->{W * netscale}x{H * netscale} frame per GPU, {name}, bf16, tile 512/10 (device-resident input)",
+           "frames_per_s": round(world * steps / el, 3), "mp_s": round(world * steps * out_mp / el, 2),
+           "ms_per_frame": round(1e3 * el / steps, 2), "tflops_whole_net": round(world * steps * flops / el / 1e12, 1),
+           "frac_of_bf16_peak_per_gpu": round(steps * flops / el / 1e12 / PEAK_TFLOPS["bf16"], 4),
+           "steps": steps, "scaling": "weak", "n_gpus": world}
+    if k_ms > 0 and k_n > 0:
+        ach = k_fl / (k_ms * 1e-3) / 1e12
+        obj["roofline"] = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_TFLOPS["bf16"], 4), "traffic": pmc_traffic(key),
+                           "kernel": ("rdb_bf16_strip_kernel: conv1..conv5 of a dense block over ALL tiles of the frame in one persistent launch, "
+                                      "x0..x4 of a workgroup's strip resident in LDS" if strip else
+                                      "conv3x3_bf16_xl_kernel (per-layer launches)"),
+                           "avg_launch_us": round(1e3 * k_ms / k_n, 2), "launches": int(k_n),
+                           "algorithmic_gflop_per_launch": round(k_fl / k_n / 1e9, 2),
+                           "note": "`achieved` = algorithmic FLOPs of the tiles' own pixels in the dense blocks / HIP-event time around them; "
+                                   "`traffic` = bytes per launch from the committed PMC passes (FETCH_SIZE x 2 + WRITE_SIZE), null when stale"}
+    return up, obj
+
+
+def c3_objects(args, dev, rank, world, timed):
+    """BASELINE.json configs[2] and [3] beside the headline: one 2160p x2plus frame sharded over the ranks (strong scaling), one
+    independent 2160p x2plus frame per GPU and one independent 1080p x4plus frame per GPU (weak scaling), bf16,
+    RealESRGANer(tile=512, tile_pad=10)."""
+    import torch
+    from neural_enhanced_super_resolution_amd import sharded
+    from neural_enhanced_super_resolution_amd.synth import synthetic_frame
+    H, W = 2160, 3840
+    up, c3s = stream_object(args, dev, rank, world, timed, 2, H, W, "c3", "RealESRGAN_x2plus")
+    out = {"c3_stream": c3s}
     steps, warm = max(2, min(args.steps, 6)), 2
     flops = up.model.forward_flops(1, H, W)
     frame = synthetic_frame(H, W, seed=0)
     band = torch.from_numpy(sharded.scatter_rows(frame, rank, world)).to(dev)
     el = timed(lambda: sharded.enhance_sharded(up, band, (H, W)), steps, warm)
-    out = {"c3": {"workload": "one 3840x2160->7680x4320 frame for the whole job, bf16, tile 512/10, tiles sharded over ranks "
-                              "(uint8 rows in, RCCL p2p overlap rows, uint8 frame gathered to rank 0's host)",
-                  "frames_per_s": round(steps / el, 3), "mp_s": round(steps * 4 * H * W / 1e6 / el, 2), "ms_per_frame": round(1e3 * el / steps, 2),
-                  "tflops_whole_net": round(steps * flops / el / 1e12, 1), "steps": steps, "scaling": "strong", "n_gpus": world}}
-    mine = synthetic_frame(H, W, seed=rank)
-    up.pre_process(np.ascontiguousarray(mine[:, :, ::-1].astype(np.float32) / 255.0))
-    el = timed(up.tile_process, steps, warm)
-    out["c3_stream"] = {"workload": "one independent 3840x2160->7680x4320 frame per GPU, bf16, tile 512/10 (device-resident input)",
-                        "frames_per_s": round(world * steps / el, 3), "mp_s": round(world * steps * 4 * H * W / 1e6 / el, 2),
-                        "tflops_whole_net": round(world * steps * flops / el / 1e12, 1),
-                        "frac_of_bf16_peak_per_gpu": round(steps * flops / el / 1e12 / PEAK_TFLOPS["bf16"], 4),
-                        "steps": steps, "scaling": "weak", "n_gpus": world}
+    out["c3"] = {"workload": "one 3840x2160->7680x4320 frame for the whole job, bf16, tile 512/10, tiles sharded over ranks "
+                             "(uint8 rows in, RCCL p2p overlap rows, uint8 frame gathered to rank 0's host)",
+                 "frames_per_s": round(steps / el, 3), "mp_s": round(steps * 4 * H * W / 1e6 / el, 2), "ms_per_frame": round(1e3 * el / steps, 2),
+                 "tflops_whole_net": round(steps * flops / el / 1e12, 1), "steps": steps, "scaling": "strong", "n_gpus": world}
     up.model.check_status()
+    del up
+    torch.cuda.empty_cache()
+    up4, c4s = stream_object(args, dev, rank, world, timed, 4, 1080, 1920, "c4", "RealESRGAN_x4plus")
+    out["c4_stream"] = c4s
+    del up4
+    torch.cuda.empty_cache()
     return out
 
 

@@ -195,11 +195,20 @@ def lab2rgb_u8(lab, linear=False, first_is_blue=False):
     return np.clip(np.rint(c * np.float32(255.0)), 0, 255).astype(np.uint8)
 
 
+def clahe_tile_size(h, w, grid=(8, 8)):
+    """(tile height, tile width) cv2's CLAHE uses for an h x w image (clahe.cpp, CLAHE_Impl::apply)."""
+    gx, gy = grid
+    ph, pw = (gy - h % gy, gx - w % gx) if (h % gy or w % gx) else (0, 0)
+    return (h + ph) // gy, (w + pw) // gx
+
+
 def clahe_u8(gray, clip_limit=2.0, grid=(8, 8)):
     """cv2.createCLAHE(clip_limit, grid).apply(gray) (clahe.cpp: CLAHE_CalcLut_Body + CLAHE_Interpolation_Body)."""
     h, w = gray.shape
     gx, gy = grid
-    ph, pw = (gy - h % gy) % gy, (gx - w % gx) % gx
+    # clahe.cpp: only when BOTH sides divide by the grid is the image used as it is; otherwise copyMakeBorder pads the bottom by
+    # tilesY - h % tilesY and the right by tilesX - w % tilesX -- a side that does divide gets a whole extra tilesY / tilesX pixels
+    ph, pw = (gy - h % gy, gx - w % gx) if (h % gy or w % gx) else (0, 0)
     src = gray
     if ph or pw:
         src = np.zeros((h + ph, w + pw), np.uint8)

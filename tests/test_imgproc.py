@@ -63,7 +63,17 @@ def test_gray_and_lab():
     assert P.rgb2lab_u8(_t(np.zeros((2, 2, 3), np.uint8))).numpy()[0, 0].tolist() == [0, 128, 128]
 
 
-@pytest.mark.parametrize("shape", [(64, 64), (50, 70)])
+def test_clahe_tile_size_follows_clahe_cpp():
+    """cv2 pads BOTH sides as soon as one of them does not divide by the grid: by tilesY - h % tilesY and tilesX - w % tilesX
+    (a full 8 extra pixels on a side that does divide) -- nesr/nesr.py:680-684 calls it on frames of any size."""
+    for mod in (P, O):
+        assert mod.clahe_tile_size(64, 64) == (8, 8)            # both divide: no padding
+        assert mod.clahe_tile_size(64, 70) == (9, 9)            # (64 + 8) / 8, (70 + 2) / 8
+        assert mod.clahe_tile_size(50, 72) == (7, 10)           # (50 + 6) / 8, (72 + 8) / 8
+        assert mod.clahe_tile_size(50, 70) == (7, 9)
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (50, 70), (64, 70), (50, 72)])
 def test_clahe(shape):
     g = synthetic_frame(shape[0], shape[1], seed=8)[:, :, 1].copy()
     got, want = P.clahe_u8(_t(g), 2.0, (8, 8)).numpy(), O.clahe_u8(g, 2.0, (8, 8))
