@@ -213,6 +213,26 @@ int nesr_check_range(nesr_ctx* ctx, void* hip_stream);
 void nesr_destroy(nesr_ctx* ctx);
 
 /*
+ * Tiled frames without the float canvas (SURVEY.md section 8(f) row 1 for frames larger than a tile).  Replaces, for all tiles of a
+ * frame at once, RealESRGANer.enhance's `img.astype(float32) / 255`, BGR->RGB and tile_process's
+ * `input_tile = self.img[:, :, y0:y1, x0:x1]` (nesr_cut_tiles_u8), and tile_process's paste of every tile's un-padded centre followed
+ * by enhance's clamp(0, 1), RGB->BGR, x255, round (nesr_paste_tiles_u8); called from standalone/direct_esrgan.py:148 with
+ * tile=512, tile_pad=10.
+ *   through_fp16 : the values pass through fp16 once: upstream's RealESRGANer(half=True) hands the network an fp16 tensor
+ *             (`self.img = self.img.half()`) and gets one back
+ *   windows : host array, n x (y0, x0, h, w): tile i = frame[y0:y0+h, x0:x0+w] into the top-left of slot i of tiles_nchw_dev
+ *             ([n, 3, Hs, Ws] f32; the rest of a slot is zeroed) -- the layout nesr_forward_ragged takes
+ *   desc    : host array, n x (crop y, crop x, h, w, destination byte offset, destination row pitch in bytes): the h x w pixels
+ *             at (crop y, crop x) of tile i's output (slot i of tiles_nchw_dev, [n, 3, Hs, Ws] f32) go to dst_dev + offset as u8 HWC
+ *             rows `pitch` bytes apart -- a window of the frame's output canvas, or a packed per-tile buffer (multi-GPU gather)
+ * 1 <= n <= 64.
+ */
+int nesr_cut_tiles_u8(int device_id, const uint8_t* frame_hwc_dev, int H, int W, int flip_rgb, int through_fp16, const int* windows, int n, int Hs,
+                      int Ws, float* tiles_nchw_dev, void* hip_stream);
+int nesr_paste_tiles_u8(int device_id, const float* tiles_nchw_dev, int n, int Hs, int Ws, const int64_t* desc, uint8_t* dst_dev, size_t dst_bytes,
+                        int flip_rgb, int round_mode, int through_fp16, void* hip_stream);
+
+/*
  * Single-layer entry (test hook for the per-layer parity tests): one 3x3 stride-1 zero-pad-1
  * convolution + bias (+ LeakyReLU(0.2) if lrelu) (+ nearest x2 upsample of the input first if
  * upsample), i.e. torch.nn.Conv2d / F.leaky_relu / F.interpolate as composed in RRDBNet.forward.

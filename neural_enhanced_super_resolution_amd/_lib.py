@@ -48,6 +48,9 @@ SIGNATURES = {
     "nesr_check_status": (_c.c_int, [_c.c_void_p]),
     "nesr_check_range": (_c.c_int, [_c.c_void_p, _c.c_void_p]),
     "nesr_destroy": (None, [_c.c_void_p]),
+    "nesr_cut_tiles_u8": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int), _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "nesr_paste_tiles_u8": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int64), _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int,
+                                       _c.c_int, _c.c_void_p]),
     "nesr_conv3x3": (_c.c_int, [_c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
                                 _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "nesr_last_error": (_c.c_char_p, []),

@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1157,6 +1158,49 @@ int nesr_band_rows(nesr_ctx* c, int buffer, int row0, int nrows, void* staging_d
         if (write) HIP_TRY(hipMemcpyAsync(src, dst, span, hipMemcpyDeviceToDevice, s));
         else HIP_TRY(hipMemcpyAsync(dst, src, span, hipMemcpyDeviceToDevice, s));
     }
+    return NESR_OK;
+}
+
+int nesr_cut_tiles_u8(int device_id, const uint8_t* frame_hwc_dev, int H, int W, int flip_rgb, int through_fp16, const int* windows, int n, int Hs, int Ws,
+                      float* tiles_nchw_dev, void* stream) {
+    if (!frame_hwc_dev || !windows || !tiles_nchw_dev) return fail(NESR_ERR_ARG, "null argument");
+    if (n < 1 || n > TILE_IO_MAX || Hs < 1 || Ws < 1) return fail(NESR_ERR_ARG, "nesr_cut_tiles_u8: 1.." + std::to_string(TILE_IO_MAX) + " tiles per call");
+    TileIo t;
+    std::memset(&t, 0, sizeof(t));
+    for (int i = 0; i < n; ++i) {
+        const int y0 = windows[4 * i], x0 = windows[4 * i + 1], h = windows[4 * i + 2], w = windows[4 * i + 3];
+        if (y0 < 0 || x0 < 0 || h < 1 || w < 1 || y0 + h > H || x0 + w > W || h > Hs || w > Ws)
+            return fail(NESR_ERR_ARG, "nesr_cut_tiles_u8: window " + std::to_string(i) + " outside the frame or larger than a slot");
+        t.desc[8 * i] = y0; t.desc[8 * i + 1] = x0; t.desc[8 * i + 2] = h; t.desc[8 * i + 3] = w;
+    }
+    t.frame = const_cast<uint8_t*>(frame_hwc_dev); t.frame_w = W; t.tiles = tiles_nchw_dev; t.Hs = Hs; t.Ws = Ws; t.flip = flip_rgb ? 1 : 0;
+    t.round = through_fp16 ? 1 : 0;
+    HIP_TRY(hipSetDevice(device_id));
+    HIP_TRY(launch_cut_tiles(t, n, Hs, Ws, static_cast<hipStream_t>(stream)));
+    return NESR_OK;
+}
+
+int nesr_paste_tiles_u8(int device_id, const float* tiles_nchw_dev, int n, int Hs, int Ws, const int64_t* desc, uint8_t* dst_dev, size_t dst_bytes,
+                        int flip_rgb, int round_mode, int through_fp16, void* stream) {
+    if (!tiles_nchw_dev || !desc || !dst_dev) return fail(NESR_ERR_ARG, "null argument");
+    if (n < 1 || n > TILE_IO_MAX || Hs < 1 || Ws < 1) return fail(NESR_ERR_ARG, "nesr_paste_tiles_u8: 1.." + std::to_string(TILE_IO_MAX) + " tiles per call");
+    TileIo t;
+    std::memset(&t, 0, sizeof(t));
+    int maxh = 0, maxw = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t* d = desc + 6 * i;      // crop y, crop x, h, w, destination offset (bytes), row pitch (bytes)
+        if (d[0] < 0 || d[1] < 0 || d[2] < 1 || d[3] < 1 || d[0] + d[2] > Hs || d[1] + d[3] > Ws || d[4] < 0 || d[5] < d[3] * 3 ||
+            (uint64_t)d[4] + (uint64_t)(d[2] - 1) * (uint64_t)d[5] + (uint64_t)d[3] * 3 > dst_bytes)
+            return fail(NESR_ERR_ARG, "nesr_paste_tiles_u8: tile " + std::to_string(i) + ": crop outside its slot or destination outside the buffer");
+        int* o = t.desc + 8 * i;
+        o[0] = (int)d[0]; o[1] = (int)d[1]; o[2] = (int)d[2]; o[3] = (int)d[3]; o[4] = (int)d[5];
+        o[5] = (int)(uint32_t)((uint64_t)d[4] & 0xffffffffull); o[6] = (int)(uint32_t)((uint64_t)d[4] >> 32);
+        maxh = std::max(maxh, (int)d[2]); maxw = std::max(maxw, (int)d[3]);
+    }
+    t.frame = dst_dev; t.tiles = const_cast<float*>(tiles_nchw_dev); t.Hs = Hs; t.Ws = Ws; t.flip = flip_rgb ? 1 : 0;
+    t.round = (round_mode == NESR_ROUND_NEAREST ? 1 : 0) | (through_fp16 ? 2 : 0);
+    HIP_TRY(hipSetDevice(device_id));
+    HIP_TRY(launch_paste_tiles(t, n, maxh, maxw, static_cast<hipStream_t>(stream)));
     return NESR_OK;
 }
 

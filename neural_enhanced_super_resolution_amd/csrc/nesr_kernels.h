@@ -206,6 +206,19 @@ struct PackArgs {
 };
 hipError_t launch_pack_input(const PackArgs& a, hipStream_t s);
 
+// all tiles of a frame at once (pack.hip): u8 HWC frame -> float NCHW tile slots (cut), float NCHW tile outputs -> u8 (paste)
+constexpr int TILE_IO_MAX = 64;
+struct TileIo {
+    uint8_t* frame;       // cut: the frame (read); paste: base of the destination
+    int frame_w;          // cut: pixels per frame row
+    float* tiles;         // [n][3][Hs][Ws]
+    int Hs, Ws;
+    int flip, round;
+    int desc[8 * TILE_IO_MAX];   // per tile: cut {y0, x0, h, w}; paste {crop y, crop x, h, w, row pitch (bytes), offset lo, offset hi}
+};
+hipError_t launch_cut_tiles(const TileIo& t, int n, int maxh, int maxw, hipStream_t s);
+hipError_t launch_paste_tiles(const TileIo& t, int n, int maxh, int maxw, hipStream_t s);
+
 // feature map (channels [0,c)) -> planar f32 NCHW; used by the single-layer test hook
 hipError_t launch_nhwc_to_nchw(const void* src, int kind /* as PackArgs::bf16 */, Map map, int n, int c, int h, int w, float* dst, hipStream_t s);
 

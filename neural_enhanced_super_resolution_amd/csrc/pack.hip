@@ -90,7 +90,52 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* src, int 
     }
 }
 
+// ---- the tiles of a frame: RealESRGANer.tile_process's `input_tile = self.img[:, :, y0:y1, x0:x1]` for every tile at once, with
+// enhance()'s `img / 255` and BGR->RGB in front (cut), and its paste of every tile's un-padded centre with enhance()'s
+// clamp(0, 1), RGB->BGR, x255 and round behind (paste) -- the float canvas of the whole frame never exists.
+__global__ __launch_bounds__(256) void cut_tiles_kernel(TileIo t) {
+    const int n = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= t.Ws) return;
+    const int* d = t.desc + 8 * n;           // y0, x0, h, w of the window in the frame
+    const bool in = y < d[2] && x < d[3];
+    float* dst = t.tiles + (((size_t)n * 3) * t.Hs + y) * t.Ws + x;
+    const uint8_t* src = t.frame + ((size_t)(d[0] + (in ? y : 0)) * t.frame_w + d[1] + (in ? x : 0)) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = in ? (float)src[t.flip ? 2 - c : c] / 255.0f : 0.f;
+        if (t.round) v = (float)(_Float16)v;      // RealESRGANer(half=True): `self.img = self.img.half()` before the tiles are cut
+        dst[(size_t)c * t.Hs * t.Ws] = v;
+    }
+}
+__global__ __launch_bounds__(256) void paste_tiles_kernel(TileIo t) {
+    const int n = blockIdx.z, y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+    const int* d = t.desc + 8 * n;           // crop origin (y, x) inside the tile's output, crop size (h, w), row pitch, offset lo / hi of the destination
+    if (y >= d[2] || x >= d[3]) return;
+    const float* src = t.tiles + (((size_t)n * 3) * t.Hs + d[0] + y) * t.Ws + d[1] + x;
+    uint8_t* dst = t.frame + (((size_t)(unsigned)d[6] << 32) | (size_t)(unsigned)d[5]) + (size_t)y * d[4] + (size_t)x * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float v = src[(size_t)c * t.Hs * t.Ws];
+        if (t.round & 2) v = (float)(_Float16)v;      // RealESRGANer(half=True): the network's output is an fp16 tensor upstream
+        float q = fminf(fmaxf(v, 0.f), 1.f) * 255.0f;
+        q = (t.round & 1) ? rintf(q) : truncf(q);
+        dst[t.flip ? 2 - c : c] = (uint8_t)q;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_cut_tiles(const TileIo& t, int n, int maxh, int maxw, hipStream_t s) {
+    (void)maxh; (void)maxw;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cut_tiles_kernel, dim3((t.Ws + 255) / 256, t.Hs, n), dim3(256), 0, s, t);
+    return hipGetLastError();
+}
+hipError_t launch_paste_tiles(const TileIo& t, int n, int maxh, int maxw, hipStream_t s) {
+    if (n <= 0 || maxh <= 0 || maxw <= 0) return hipSuccess;
+    hipLaunchKernelGGL(paste_tiles_kernel, dim3((maxw + 255) / 256, maxh, n), dim3(256), 0, s, t);
+    return hipGetLastError();
+}
 
 hipError_t launch_pack_input(const PackArgs& a, hipStream_t s) {
     const size_t total = (size_t)a.n * (a.hin / a.unshuffle) * (a.win / a.unshuffle);

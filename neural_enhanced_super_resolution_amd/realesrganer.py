@@ -404,8 +404,49 @@ class RealESRGANer:
         return (isinstance(self.model, RRDBNet) and self.device.type == "cuda" and img.dtype == np.uint8
                 and img.ndim == 3 and img.shape[2] == 3)
 
+    def _u8_tiles_fused_ok(self, h, w):
+        """8-bit frames larger than a tile whose tiles run as ragged batches (bf16, strip kernel): cut and paste are one launch
+        each and the float canvas of the frame never exists.  Frames that need the reflect pre-pad / mod-pad keep the general path."""
+        ms = {2: 2, 1: 4}.get(self.scale, 1)
+        return (self.tile_size > 0 and self.pre_pad == 0 and h % ms == 0 and w % ms == 0 and isinstance(self.model, RRDBNet)
+                and self.model.compute_dtype == "bf16" and self.model.strip_kernel_active() and self.ragged_tiles is None
+                and self.model.out_scale() == self.scale)
+
+    @torch.no_grad()
+    def tiles_u8_on_device(self, frame_u8, windows, pastes, dst_u8):
+        """frame_u8 [H, W, 3] uint8 on the device; windows [(y0, x0, h, w)] of the padded tiles; pastes [(crop_y, crop_x, h, w, dst byte
+        offset, dst row pitch)] -> the tiles' quantised centres in dst_u8 (uint8, on the device).  Ragged batches of at most
+        RAGGED_MAX tiles: cut (nesr_cut_tiles_u8), forward_ragged, paste (nesr_paste_tiles_u8)."""
+        from .rrdbnet import cut_tiles_u8, paste_tiles_u8
+        cap = max(1, min(self.model.RAGGED_MAX, int(self.ragged_batch)))
+        for i in range(0, len(windows), cap):
+            win, pst = windows[i:i + cap], pastes[i:i + cap]
+            hs, ws = max(v[2] for v in win), max(v[3] for v in win)
+            x = cut_tiles_u8(frame_u8, win, (hs, ws), flip_rgb=True, through_fp16=bool(self.half))
+            out = self.model.forward_ragged(x, [(v[2], v[3]) for v in win])
+            paste_tiles_u8(out, pst, dst_u8, flip_rgb=True, round_nearest=True, through_fp16=bool(self.half))
+
+    @torch.no_grad()
+    def _enhance_u8_tiles_fused(self, img):
+        h, w = img.shape[:2]
+        s = self.scale
+        frame = torch.from_numpy(np.ascontiguousarray(img)).to(self.device)          # H2D: uint8 HWC BGR
+        canvas = torch.empty((h * s, w * s, 3), dtype=torch.uint8, device=self.device)
+        windows, pastes = [], []
+        for (py0, py1, px0, px1), (oy0, oy1, ox0, ox1), (cy0, cy1, cx0, cx1) in self.tile_grid(h, w):
+            windows.append((py0, px0, py1 - py0, px1 - px0))
+            pastes.append((cy0, cx0, cy1 - cy0, cx1 - cx0, (oy0 * w * s + ox0) * 3, w * s * 3))
+        self.tiles_u8_on_device(frame, windows, pastes, canvas)
+        host = torch.empty(canvas.shape, dtype=torch.uint8, pin_memory=True)          # (the caching host allocator recycles these)
+        host.copy_(canvas, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        self._check_range()
+        return host.numpy()
+
     @torch.no_grad()
     def _enhance_u8_on_device(self, img):
+        if self._u8_tiles_fused_ok(img.shape[0], img.shape[1]) and (img.shape[0] > self.tile_size or img.shape[1] > self.tile_size):
+            return self._enhance_u8_tiles_fused(img)
         x = torch.from_numpy(np.ascontiguousarray(img)).to(self.device)            # H2D: uint8 HWC BGR
         x = normalize_u8_on_device(x.permute(2, 0, 1).flip(0)).unsqueeze(0)          # BGR->RGB, /255 (f32), HWC->NCHW
         self._pad_on_device(x)

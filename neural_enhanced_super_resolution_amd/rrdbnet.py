@@ -519,6 +519,46 @@ class RRDBNet(nn.Module):
         return tot_ms, tot_n, tot_fl
 
 
+def cut_tiles_u8(frame_u8, windows, slot_hw, flip_rgb=True, through_fp16=False):
+    """All tiles of a frame in one launch: u8 HWC [H, W, 3] device tensor -> float32 [n, 3, Hs, Ws], tile i =
+    frame[y0:y0+h, x0:x0+w] / 255 (BGR -> RGB if flip_rgb) in the top-left of slot i, zeros elsewhere -- what
+    RealESRGANer.enhance + tile_process feed the network (include/nesr_hip.h: nesr_cut_tiles_u8).  windows: [(y0, x0, h, w)]."""
+    if frame_u8.device.type != "cuda" or frame_u8.dtype != torch.uint8 or frame_u8.dim() != 3 or frame_u8.shape[2] != 3:
+        raise ValueError("cut_tiles_u8: a uint8 [H, W, 3] tensor on the ROCm device")
+    f = frame_u8.contiguous()
+    n = len(windows)
+    hs, ws = int(slot_hw[0]), int(slot_hw[1])
+    x = torch.empty((n, 3, hs, ws), dtype=torch.float32, device=f.device)
+    arr = (ctypes.c_int * (4 * n))(*[int(v) for win in windows for v in win])
+    index = f.device.index if f.device.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(f.device):
+        stream = torch.cuda.current_stream(f.device).cuda_stream
+        _lib.check(_lib.load().nesr_cut_tiles_u8(index, ctypes.c_void_p(f.data_ptr()), f.shape[0], f.shape[1], 1 if flip_rgb else 0,
+                                                 1 if through_fp16 else 0, arr, n, hs, ws, ctypes.c_void_p(x.data_ptr()),
+                                                 ctypes.c_void_p(stream)), "nesr_cut_tiles_u8")
+    return x
+
+
+def paste_tiles_u8(tiles, descs, dst_u8, flip_rgb=True, round_nearest=True, through_fp16=False):
+    """The un-padded centres of all tiles in one launch: tiles float32 [n, 3, Hs, Ws] (network outputs in their slots) ->
+    clamp(0, 1), RGB -> BGR, x255, round, into the uint8 device tensor dst_u8 (a frame's output canvas [H, W, 3], or any flat
+    buffer).  descs: [(crop_y, crop_x, h, w, dst_byte_offset, dst_row_pitch_bytes)] (nesr_paste_tiles_u8)."""
+    if tiles.device.type != "cuda" or tiles.dtype != torch.float32 or tiles.dim() != 4 or tiles.shape[1] != 3 or not tiles.is_contiguous():
+        raise ValueError("paste_tiles_u8: a contiguous float32 [n, 3, Hs, Ws] tensor on the ROCm device")
+    if dst_u8.dtype != torch.uint8 or not dst_u8.is_contiguous() or dst_u8.device != tiles.device:
+        raise ValueError("paste_tiles_u8: a contiguous uint8 destination on the same device")
+    n = tiles.shape[0]
+    arr = (ctypes.c_int64 * (6 * n))(*[int(v) for d in descs for v in d])
+    index = tiles.device.index if tiles.device.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(tiles.device):
+        stream = torch.cuda.current_stream(tiles.device).cuda_stream
+        _lib.check(_lib.load().nesr_paste_tiles_u8(index, ctypes.c_void_p(tiles.data_ptr()), n, tiles.shape[2], tiles.shape[3], arr,
+                                                   ctypes.c_void_p(dst_u8.data_ptr()), dst_u8.numel(), 1 if flip_rgb else 0,
+                                                   _lib.ROUND_NEAREST if round_nearest else _lib.ROUND_TRUNC, 1 if through_fp16 else 0,
+                                                   ctypes.c_void_p(stream)),
+                   "nesr_paste_tiles_u8")
+
+
 def conv3x3(x, weight, bias, lrelu=False, upsample=False, dtype="f32"):
     """Single fused layer through the C ABI (test hook): conv3x3(pad 1) + bias [+ LeakyReLU(0.2)],
     optionally on the nearest-x2 upsample of x.  x NCHW float32 on a ROCm device."""

@@ -134,8 +134,26 @@ def enhance_sharded(up, band, frame_hw, group=None, gather=True):
 
     # ---- this rank's tiles: same arithmetic as RealESRGANer.enhance / tile_process
     mine = [t for t, o in zip(tiles, owner) if o == rank]
+    fused = bool(mine) and hasattr(up, "_u8_tiles_fused_ok") and up._u8_tiles_fused_ok(H, W) and up.tile_size > 0
     results = []
-    if mine:
+    if mine and fused:
+        # cut / ragged forward / paste, one launch each per batch (RealESRGANer.tiles_u8_on_device): on rank 0 straight into the
+        # frame's canvas, elsewhere into one packed buffer whose slices are sent
+        windows = [(t.inp[0] - n0, t.inp[2], t.inp[1] - t.inp[0], t.inp[3] - t.inp[2]) for t in mine]
+        if rank == 0 and gather:
+            canvas = torch.empty((H * s, W * s, 3), dtype=torch.uint8, device=dev)
+            pastes = [(t.crop[0], t.crop[2], t.crop[1] - t.crop[0], t.crop[3] - t.crop[2], (t.out[0] * W * s + t.out[2]) * 3, W * s * 3) for t in mine]
+            up.tiles_u8_on_device(local, windows, pastes, canvas)
+        else:
+            sizes = [(t.out[1] - t.out[0]) * (t.out[3] - t.out[2]) * 3 for t in mine]
+            offs = [0]
+            for v in sizes:
+                offs.append(offs[-1] + v)
+            packed = torch.empty((offs[-1],), dtype=torch.uint8, device=dev)
+            pastes = [(t.crop[0], t.crop[2], t.crop[1] - t.crop[0], t.crop[3] - t.crop[2], offs[i], (t.out[3] - t.out[2]) * 3) for i, t in enumerate(mine)]
+            up.tiles_u8_on_device(local, windows, pastes, packed)
+            results = [(t, packed[offs[i]:offs[i + 1]].view(t.out[1] - t.out[0], t.out[3] - t.out[2], 3)) for i, t in enumerate(mine)]
+    elif mine:
         x = normalize_u8_on_device(local.permute(2, 0, 1).flip(0)).unsqueeze(0)   # BGR->RGB, /255, HWC->NCHW
         if up.half:
             x = x.half()
@@ -150,9 +168,10 @@ def enhance_sharded(up, band, frame_hw, group=None, gather=True):
 
     # ---- gather quantised tiles on rank 0
     if rank == 0:
-        canvas = torch.zeros((H * s, W * s, 3), dtype=torch.uint8, device=dev)
-        for t, q in results:
-            canvas[t.out[0]:t.out[1], t.out[2]:t.out[3]] = q
+        if not (mine and fused):
+            canvas = torch.zeros((H * s, W * s, 3), dtype=torch.uint8, device=dev)
+            for t, q in results:
+                canvas[t.out[0]:t.out[1], t.out[2]:t.out[3]] = q
         bufs, ops = [], []
         for t, o in zip(tiles, owner):
             if o != 0:
@@ -162,9 +181,16 @@ def enhance_sharded(up, band, frame_hw, group=None, gather=True):
         _p2p(ops)
         for t, buf in bufs:
             canvas[t.out[0]:t.out[1], t.out[2]:t.out[3]] = buf
+        if dev.type == "cuda":
+            host = torch.empty(canvas.shape, dtype=torch.uint8, pin_memory=True)
+            host.copy_(canvas, non_blocking=True)
+            torch.cuda.current_stream(dev).synchronize()
+            if hasattr(up, "_check_range"):
+                up._check_range()
+            return host.numpy()
         return canvas.cpu().numpy()
     results.sort(key=lambda r: r[0].index)
-    _p2p([dist.P2POp(dist.isend, q, 0, group) for _, q in results])
+    _p2p([dist.P2POp(dist.isend, q.contiguous(), 0, group) for _, q in results])
     return None
 
 

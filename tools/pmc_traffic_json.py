@@ -24,7 +24,7 @@ def total(d, counter):
     rows = []
     for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
         rows += [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
-    fused = [r for r in rows if "rdb_f16x2" in r["Kernel_Name"]]
+    fused = [r for r in rows if "rdb_f16x2" in r["Kernel_Name"] or "rdb_bf16_strip" in r["Kernel_Name"]]
     sel = fused if fused else [r for r in rows if "conv3x3" in r["Kernel_Name"]]
     return len(sel), sum(float(r["Counter_Value"]) for r in sel)
 
