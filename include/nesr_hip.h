@@ -233,6 +233,30 @@ int nesr_paste_tiles_u8(int device_id, const float* tiles_nchw_dev, int n, int H
                         int flip_rgb, int round_mode, int through_fp16, void* hip_stream);
 
 /*
+ * Sharded frames (SURVEY.md section 8(b), 8(e) mode 1): one process per GPU, RCCL point to point over xGMI, no collective.  Stands
+ * behind `upscaler.enhance(img)` of standalone/direct_esrgan.py:148 (RealESRGANer(tile=512, tile_pad=10), :118-127) when one frame is
+ * evaluated by several GPUs: the tiles of upstream's grid are independent network evaluations, dealt to the ranks in contiguous
+ * runs balanced by padded area; the uint8 frame is row-scattered (rank r holds rows [r H / N, (r + 1) H / N)) and a rank fetches only
+ * the rows its tiles read beyond its band; quantised tile centres are gathered on rank 0.
+ *   nesr_comm_unique_id : rank 0 fills 128 bytes the host distributes by its own means (the launcher's rendezvous)
+ *   nesr_comm_init      : every rank, with its rank / the world size / those 128 bytes (ncclCommInitRank on the context's device);
+ *                         librccl.so is loaded on the first of these calls, never before
+ *   nesr_forward_sharded_u8 : band_dev = this rank's rows of the u8 HWC BGR frame (device memory); out_dev (rank 0 only) = the
+ *                         [H s, W s, 3] u8 BGR result; enqueued on hip_stream.  Without nesr_comm_init it is the one-rank case.
+ *                         through_fp16 as in nesr_cut_tiles_u8 / nesr_paste_tiles_u8.  bf16 contexts.
+ *   nesr_shard_plan     : the plan by itself (host only, no device): tiles as 13 ints each (input window y0 y1 x0 x1, output window,
+ *                         crop inside the tile's output, owner rank) and the row moves (src, dst, row lo, row hi); counts are always
+ *                         returned, the arrays are filled when they are large enough.  `scale` = output / input size.
+ */
+int nesr_comm_unique_id(void* id128);
+int nesr_comm_init(nesr_ctx* ctx, int rank, int nranks, const void* id128);
+int nesr_comm_destroy(nesr_ctx* ctx);
+int nesr_forward_sharded_u8(nesr_ctx* ctx, const uint8_t* band_dev, int H, int W, int tile, int tile_pad, int through_fp16, uint8_t* out_dev,
+                            void* hip_stream);
+int nesr_shard_plan(int H, int W, int scale, int tile, int tile_pad, int nranks, int* tiles13, int cap_tiles, int* ntiles, int* moves4,
+                    int cap_moves, int* nmoves);
+
+/*
  * Single-layer entry (test hook for the per-layer parity tests): one 3x3 stride-1 zero-pad-1
  * convolution + bias (+ LeakyReLU(0.2) if lrelu) (+ nearest x2 upsample of the input first if
  * upsample), i.e. torch.nn.Conv2d / F.leaky_relu / F.interpolate as composed in RRDBNet.forward.

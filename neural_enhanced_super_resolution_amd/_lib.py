@@ -51,6 +51,12 @@ SIGNATURES = {
     "nesr_cut_tiles_u8": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int), _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "nesr_paste_tiles_u8": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int64), _c.c_void_p, _c.c_size_t, _c.c_int, _c.c_int,
                                        _c.c_int, _c.c_void_p]),
+    "nesr_comm_unique_id": (_c.c_int, [_c.c_void_p]),
+    "nesr_comm_init": (_c.c_int, [_c.c_void_p, _c.c_int, _c.c_int, _c.c_void_p]),
+    "nesr_comm_destroy": (_c.c_int, [_c.c_void_p]),
+    "nesr_forward_sharded_u8": (_c.c_int, [_c.c_void_p, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "nesr_shard_plan": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int), _c.c_int, _c.POINTER(_c.c_int),
+                                   _c.POINTER(_c.c_int), _c.c_int, _c.POINTER(_c.c_int)]),
     "nesr_conv3x3": (_c.c_int, [_c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
                                 _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "nesr_last_error": (_c.c_char_p, []),

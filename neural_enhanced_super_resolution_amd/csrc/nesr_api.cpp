@@ -6,6 +6,7 @@
 // standalone/direct_esrgan.py:104-148.
 #include "../../include/nesr_hip.h"
 
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -98,6 +99,11 @@ struct nesr_ctx {
     bool strip_used = false;         // a strip launch went out since the last status check
     unsigned long long strip_timeout_ticks = 20000000ull;   // 200 ms of s_memrealtime: what an inter-workgroup wait of a persistent kernel may take
     int rdb_mode_init = -1, strip_mode_init = -1;
+    // sharded frames (nesr_comm_init / nesr_forward_sharded_u8): RCCL communicator + scratch
+    void* comm = nullptr;            // ncclComm_t
+    int comm_rank = 0, comm_nranks = 1;
+    char* shard_buf = nullptr;
+    size_t shard_bytes = 0;
     int debug_drop = 0;              // nesr_debug_fault: workgroups the next persistent launch leaves out
     int fused_aborts = 0;            // persistent launches that gave up (the context runs per-layer launches from then on)
     struct StripPlan {
@@ -1058,6 +1064,8 @@ void nesr_destroy(nesr_ctx* c) {
     if (c->d_weights) (void)hipFree(c->d_weights);
     if (c->d_trunk) (void)hipFree(c->d_trunk);
     if (c->d_strip) (void)hipFree(c->d_strip);
+    if (c->shard_buf) (void)hipFree(c->shard_buf);
+    if (c->comm) (void)nesr_comm_destroy(c);
     free_strip_plans(c);
     lease_forget(c);
     if (c->d_status) (void)hipFree(c->d_status);
@@ -1279,6 +1287,296 @@ int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, in
         if (flag) return fail(NESR_ERR_RANGE, "input or output of the layer was non-finite or exceeded 65504 in magnitude (f16-pair form)");
         for (size_t i = 0; i < (size_t)Cout * Cin * 9; ++i)
             if (!(std::fabs(w_host[i]) <= 65504.f)) return fail(NESR_ERR_RANGE, "weight does not fit the f16-pair form (|w| > 65504 or non-finite)");
+    }
+    return NESR_OK;
+}
+
+}  // extern "C"
+
+// ======================================================================================================================
+// Sharded frames below Python (SURVEY.md section 8(b), 8(e) mode 1): one process per GPU, the tiles of upstream's tile grid
+// dealt to the ranks, the input frame row-scattered; a rank fetches the rows its tiles read beyond its own band from the owning
+// ranks (RCCL point to point over xGMI: grouped ncclSend / ncclRecv), evaluates its tiles (cut -> ragged forward -> paste) and
+// sends their quantised centres to rank 0.  No collective: tiles are independent network evaluations
+// (RealESRGANer.tile_process, standalone/direct_esrgan.py:118-127,148).  neural_enhanced_super_resolution_amd/sharded.py is the same
+// protocol over torch.distributed; nesr_shard_plan is tested against it plan for plan.
+namespace {
+
+// RCCL is loaded on first use (librccl.so is 570 MB; a single-GPU user never pays for it, and the library loads without it)
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, /* ncclUniqueId by value: 128 bytes */ struct Id128, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+struct Id128 { char b[128]; };
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+int rccl_load() {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (g_rccl.lib) return NESR_OK;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return fail(NESR_ERR_STATE, std::string("RCCL is not loadable (librccl.so): ") + dlerror());
+#define RSYM(field, name)                                                                    \
+    *reinterpret_cast<void**>(&g_rccl.field) = dlsym(h, name);                               \
+    if (!g_rccl.field) return fail(NESR_ERR_STATE, std::string("librccl.so lacks ") + name);
+    RSYM(GetUniqueId, "ncclGetUniqueId")
+    RSYM(CommInitRank, "ncclCommInitRank")
+    RSYM(CommDestroy, "ncclCommDestroy")
+    RSYM(Send, "ncclSend")
+    RSYM(Recv, "ncclRecv")
+    RSYM(GroupStart, "ncclGroupStart")
+    RSYM(GroupEnd, "ncclGroupEnd")
+    RSYM(GetErrorString, "ncclGetErrorString")
+#undef RSYM
+    g_rccl.lib = h;
+    return NESR_OK;
+}
+#define RCCL_TRY(expr)                                                                                              \
+    do {                                                                                                            \
+        const int r__ = (expr);                                                                                     \
+        if (r__ != 0) return fail(NESR_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r__));          \
+    } while (0)
+constexpr int NCCL_UINT8 = 1;      // ncclUint8 (rccl.h: ncclInt8 = 0, ncclUint8 = 1)
+
+struct ShardTile { int inp[4], out[4], crop[4], owner; long area() const { return (long)(inp[1] - inp[0]) * (inp[3] - inp[2]); } };
+
+// RealESRGANer.tile_grid + sharded.plan_tiles: upstream's windows in its order; contiguous runs of tiles per rank, balanced by padded
+// input area (a tile goes to the next rank once its midpoint passes the rank's share)
+std::vector<ShardTile> shard_tiles(int H, int W, int s, int tile, int pad, int world) {
+    std::vector<ShardTile> v;
+    if (tile <= 0) {
+        ShardTile t{{0, H, 0, W}, {0, H * s, 0, W * s}, {0, H * s, 0, W * s}, 0};
+        v.push_back(t);
+    } else {
+        const int tx = (W + tile - 1) / tile, ty = (H + tile - 1) / tile;
+        for (int y = 0; y < ty; ++y)
+            for (int x = 0; x < tx; ++x) {
+                const int ix0 = x * tile, iy0 = y * tile, ix1 = std::min(ix0 + tile, W), iy1 = std::min(iy0 + tile, H);
+                const int px0 = std::max(ix0 - pad, 0), px1 = std::min(ix1 + pad, W), py0 = std::max(iy0 - pad, 0), py1 = std::min(iy1 + pad, H);
+                const int cx0 = (ix0 - px0) * s, cy0 = (iy0 - py0) * s;
+                ShardTile t{{py0, py1, px0, px1}, {iy0 * s, iy1 * s, ix0 * s, ix1 * s}, {cy0, cy0 + (iy1 - iy0) * s, cx0, cx0 + (ix1 - ix0) * s}, 0};
+                v.push_back(t);
+            }
+    }
+    double total = 0;
+    for (auto& t : v) total += (double)t.area();
+    double acc = 0;
+    int r = 0;
+    for (auto& t : v) {
+        while (r < world - 1 && acc + (double)t.area() / 2 > (double)(r + 1) * total / world) ++r;
+        t.owner = r;
+        acc += (double)t.area();
+    }
+    return v;
+}
+void rows_needed(const std::vector<ShardTile>& v, int rank, int& n0, int& n1) {
+    n0 = n1 = 0;
+    bool any = false;
+    for (const auto& t : v)
+        if (t.owner == rank) {
+            n0 = any ? std::min(n0, t.inp[0]) : t.inp[0];
+            n1 = any ? std::max(n1, t.inp[1]) : t.inp[1];
+            any = true;
+        }
+}
+struct RowMove { int src, dst, lo, hi; };
+std::vector<RowMove> shard_exchange(const std::vector<ShardTile>& v, int world, int H) {
+    std::vector<RowMove> plan;
+    for (int d = 0; d < world; ++d) {
+        int n0, n1;
+        rows_needed(v, d, n0, n1);
+        for (int sr = 0; sr < world; ++sr) {
+            if (sr == d) continue;
+            const int b0 = (int)((long)sr * H / world), b1 = (int)((long)(sr + 1) * H / world);
+            const int lo = std::max(n0, b0), hi = std::min(n1, b1);
+            if (lo < hi) plan.push_back({sr, d, lo, hi});
+        }
+    }
+    return plan;
+}
+
+int ensure_shard_buf(nesr_ctx* c, size_t bytes) {
+    if (bytes <= c->shard_bytes) return NESR_OK;
+    if (c->shard_buf) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(c->shard_buf)); c->shard_buf = nullptr; c->shard_bytes = 0; }
+    void* p = nullptr;
+    const hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(NESR_ERR_NOMEM, "hipMalloc(shard scratch " + std::to_string(bytes) + " B): " + hipGetErrorString(e));
+    c->shard_buf = static_cast<char*>(p);
+    c->shard_bytes = bytes;
+    return NESR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nesr_shard_plan(int H, int W, int scale, int tile, int tile_pad, int nranks, int* tiles13, int cap_tiles, int* ntiles, int* moves4, int cap_moves,
+                    int* nmoves) {
+    if (H < 1 || W < 1 || scale < 1 || tile < 0 || tile_pad < 0 || nranks < 1 || !ntiles || !nmoves) return fail(NESR_ERR_ARG, "nesr_shard_plan: bad argument");
+    const auto v = shard_tiles(H, W, scale, tile, tile_pad, nranks);
+    const auto m = shard_exchange(v, nranks, H);
+    *ntiles = (int)v.size();
+    *nmoves = (int)m.size();
+    if (tiles13 && (int)v.size() <= cap_tiles)
+        for (size_t i = 0; i < v.size(); ++i) {
+            for (int k = 0; k < 4; ++k) { tiles13[13 * i + k] = v[i].inp[k]; tiles13[13 * i + 4 + k] = v[i].out[k]; tiles13[13 * i + 8 + k] = v[i].crop[k]; }
+            tiles13[13 * i + 12] = v[i].owner;
+        }
+    if (moves4 && (int)m.size() <= cap_moves)
+        for (size_t i = 0; i < m.size(); ++i) { moves4[4 * i] = m[i].src; moves4[4 * i + 1] = m[i].dst; moves4[4 * i + 2] = m[i].lo; moves4[4 * i + 3] = m[i].hi; }
+    return NESR_OK;
+}
+
+int nesr_comm_unique_id(void* id128) {
+    if (!id128) return fail(NESR_ERR_ARG, "null id");
+    int rc = rccl_load();
+    if (rc) return rc;
+    RCCL_TRY(g_rccl.GetUniqueId(id128));
+    return NESR_OK;
+}
+
+int nesr_comm_init(nesr_ctx* c, int rank, int nranks, const void* id128) {
+    if (!c || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(NESR_ERR_ARG, "nesr_comm_init: bad argument");
+    int rc = rccl_load();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->comm) { RCCL_TRY(g_rccl.CommDestroy(c->comm)); c->comm = nullptr; }
+    Id128 id;
+    std::memcpy(id.b, id128, 128);
+    RCCL_TRY(g_rccl.CommInitRank(&c->comm, nranks, id, rank));
+    c->comm_rank = rank;
+    c->comm_nranks = nranks;
+    return NESR_OK;
+}
+
+int nesr_comm_destroy(nesr_ctx* c) {
+    if (!c) return fail(NESR_ERR_ARG, "null ctx");
+    if (c->comm) { RCCL_TRY(g_rccl.CommDestroy(c->comm)); c->comm = nullptr; }
+    c->comm_rank = 0;
+    c->comm_nranks = 1;
+    return NESR_OK;
+}
+
+int nesr_forward_sharded_u8(nesr_ctx* c, const uint8_t* band_dev, int H, int W, int tile, int tile_pad, int through_fp16, uint8_t* out_dev, void* stream) {
+    if (!c || !band_dev) return fail(NESR_ERR_ARG, "null argument");
+    const int world = c->comm ? c->comm_nranks : 1, rank = c->comm ? c->comm_rank : 0;
+    const int u = c->ufac(), s = 4 / u;
+    if (c->cin0 != 3 * u * u || c->nout != 3) return fail(NESR_ERR_ARG, "nesr_forward_sharded_u8 needs a 3-channel-in / 3-channel-out network");
+    if (H < 1 || W < 1 || H % u || W % u || tile < 0 || tile_pad < 0) return fail(NESR_ERR_ARG, "nesr_forward_sharded_u8: frame sides must be multiples of the unshuffle factor");
+    if (rank == 0 && !out_dev) return fail(NESR_ERR_ARG, "rank 0 needs the output canvas");
+    if (c->dtype != NESR_DTYPE_BF16) return fail(NESR_ERR_ARG, "nesr_forward_sharded_u8: compute dtype bf16 (ragged tile batches)");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const auto tiles = shard_tiles(H, W, s, tile, tile_pad, world);
+    const auto moves = shard_exchange(tiles, world, H);
+    int n0, n1;
+    rows_needed(tiles, rank, n0, n1);
+    const int b0 = (int)((long)rank * H / world), b1 = (int)((long)(rank + 1) * H / world);
+    std::vector<const ShardTile*> mine;
+    int hs = 0, ws = 0;
+    size_t packed = 0;
+    for (const auto& t : tiles)
+        if (t.owner == rank) {
+            mine.push_back(&t);
+            hs = std::max(hs, t.inp[1] - t.inp[0]);
+            ws = std::max(ws, t.inp[3] - t.inp[2]);
+            packed += (size_t)(t.out[1] - t.out[0]) * (t.out[3] - t.out[2]) * 3;
+        }
+    size_t remote = 0;      // rank 0: bytes of the other ranks' tiles
+    if (rank == 0)
+        for (const auto& t : tiles)
+            if (t.owner != 0) remote += (size_t)(t.out[1] - t.out[0]) * (t.out[3] - t.out[2]) * 3;
+    // scratch: [local rows | x tiles | y tiles | packed results (ranks > 0) or remote staging (rank 0)]
+    const size_t row_bytes = (size_t)W * 3;
+    const size_t local_bytes = align_up((size_t)std::max(n1 - n0, 0) * row_bytes, 256);
+    const int batch = (int)std::min<size_t>(mine.size(), std::min(TILE_IO_MAX, (int)RAG_MAX));
+    const size_t x_bytes = align_up((size_t)batch * 3 * hs * ws * 4, 256), y_bytes = align_up((size_t)batch * 3 * hs * s * ws * s * 4, 256);
+    const size_t tail_bytes = align_up(rank == 0 ? remote : packed, 256);
+    int rc = ensure_shard_buf(c, local_bytes + x_bytes + y_bytes + tail_bytes + 256);
+    if (rc) return rc;
+    uint8_t* local = reinterpret_cast<uint8_t*>(c->shard_buf);
+    float* xt = reinterpret_cast<float*>(c->shard_buf + local_bytes);
+    float* yt = reinterpret_cast<float*>(c->shard_buf + local_bytes + x_bytes);
+    uint8_t* tailb = reinterpret_cast<uint8_t*>(c->shard_buf + local_bytes + x_bytes + y_bytes);
+    // ---- own rows, then the rows of other bands (overlap rows and whatever the balanced assignment shifts across a band edge)
+    {
+        const int lo = std::max(n0, b0), hi = std::min(n1, b1);
+        if (lo < hi) HIP_TRY(hipMemcpyAsync(local + (size_t)(lo - n0) * row_bytes, band_dev + (size_t)(lo - b0) * row_bytes, (size_t)(hi - lo) * row_bytes, hipMemcpyDeviceToDevice, st));
+    }
+    if (world > 1) {
+        RCCL_TRY(g_rccl.GroupStart());
+        for (const auto& m : moves) {
+            if (m.src == rank) RCCL_TRY(g_rccl.Send(band_dev + (size_t)(m.lo - b0) * row_bytes, (size_t)(m.hi - m.lo) * row_bytes, NCCL_UINT8, m.dst, c->comm, st));
+            else if (m.dst == rank) RCCL_TRY(g_rccl.Recv(local + (size_t)(m.lo - n0) * row_bytes, (size_t)(m.hi - m.lo) * row_bytes, NCCL_UINT8, m.src, c->comm, st));
+        }
+        RCCL_TRY(g_rccl.GroupEnd());
+    }
+    // ---- this rank's tiles: cut -> ragged forward -> paste (rank 0: into the canvas; others: packed, tile after tile)
+    size_t poff = 0;
+    for (size_t i0 = 0; i0 < mine.size(); i0 += batch) {
+        const int n = (int)std::min<size_t>(batch, mine.size() - i0);
+        TileIo cut, pst;
+        std::memset(&cut, 0, sizeof(cut));
+        std::memset(&pst, 0, sizeof(pst));
+        std::vector<int> hw(2 * (size_t)n);
+        int bh = 0, bw = 0, ph = 0, pw = 0;
+        for (int i = 0; i < n; ++i) {
+            const ShardTile& t = *mine[i0 + i];
+            bh = std::max(bh, t.inp[1] - t.inp[0]);
+            bw = std::max(bw, t.inp[3] - t.inp[2]);
+        }
+        for (int i = 0; i < n; ++i) {
+            const ShardTile& t = *mine[i0 + i];
+            int* d = cut.desc + 8 * i;
+            d[0] = t.inp[0] - n0; d[1] = t.inp[2]; d[2] = t.inp[1] - t.inp[0]; d[3] = t.inp[3] - t.inp[2];
+            hw[2 * i] = d[2]; hw[2 * i + 1] = d[3];
+            int* o = pst.desc + 8 * i;
+            o[0] = t.crop[0]; o[1] = t.crop[2]; o[2] = t.crop[1] - t.crop[0]; o[3] = t.crop[3] - t.crop[2];
+            size_t off;
+            if (rank == 0) { off = ((size_t)t.out[0] * W * s + t.out[2]) * 3; o[4] = W * s * 3; }
+            else { off = poff; o[4] = o[3] * 3; poff += (size_t)o[2] * o[3] * 3; }
+            o[5] = (int)(uint32_t)(off & 0xffffffffull); o[6] = (int)(uint32_t)(off >> 32);
+            ph = std::max(ph, o[2]); pw = std::max(pw, o[3]);
+        }
+        cut.frame = local; cut.frame_w = W; cut.tiles = xt; cut.Hs = bh; cut.Ws = bw; cut.flip = 1; cut.round = through_fp16 ? 1 : 0;
+        HIP_TRY(launch_cut_tiles(cut, n, bh, bw, st));
+        if ((rc = nesr_forward_ragged(c, xt, n, 3, bh, bw, hw.data(), yt, stream))) return rc;
+        pst.frame = rank == 0 ? out_dev : tailb; pst.tiles = yt; pst.Hs = bh * s; pst.Ws = bw * s; pst.flip = 1; pst.round = 1 | (through_fp16 ? 2 : 0);
+        HIP_TRY(launch_paste_tiles(pst, n, ph, pw, st));
+    }
+    // ---- gather on rank 0: one message per rank (its tiles packed in tile order), scattered into the canvas
+    if (world > 1) {
+        std::vector<size_t> rank_bytes(world, 0), rank_off(world, 0);
+        for (const auto& t : tiles) rank_bytes[t.owner] += (size_t)(t.out[1] - t.out[0]) * (t.out[3] - t.out[2]) * 3;
+        size_t o = 0;
+        for (int r = 1; r < world; ++r) { rank_off[r] = o; o += rank_bytes[r]; }
+        RCCL_TRY(g_rccl.GroupStart());
+        if (rank == 0) {
+            for (int r = 1; r < world; ++r)
+                if (rank_bytes[r]) RCCL_TRY(g_rccl.Recv(tailb + rank_off[r], rank_bytes[r], NCCL_UINT8, r, c->comm, st));
+        } else if (rank_bytes[rank]) {
+            RCCL_TRY(g_rccl.Send(tailb, rank_bytes[rank], NCCL_UINT8, 0, c->comm, st));
+        }
+        RCCL_TRY(g_rccl.GroupEnd());
+        if (rank == 0) {
+            std::vector<size_t> cur(rank_off);
+            for (const auto& t : tiles) {
+                if (t.owner == 0) continue;
+                const size_t th = t.out[1] - t.out[0], tw3 = (size_t)(t.out[3] - t.out[2]) * 3;
+                HIP_TRY(hipMemcpy2DAsync(out_dev + ((size_t)t.out[0] * W * s + t.out[2]) * 3, (size_t)W * s * 3, tailb + cur[t.owner], tw3, tw3, th,
+                                         hipMemcpyDeviceToDevice, st));
+                cur[t.owner] += th * tw3;
+            }
+        }
     }
     return NESR_OK;
 }

@@ -328,6 +328,38 @@ class RRDBNet(nn.Module):
                                                    ctypes.c_void_p(stream)), "nesr_forward_u8")
         return y
 
+    # ------------------------------------------------------------------ sharded frames through the C ABI (RCCL below Python)
+    def comm_init(self, device, rank, nranks, unique_id: bytes):
+        """ncclCommInitRank for this model's context on `device` (include/nesr_hip.h: nesr_comm_init); `unique_id` = the 128 bytes
+        rank 0 got from comm_unique_id(), distributed by the caller."""
+        ctx = self._context(torch.device(device))
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        _lib.check(_lib.load().nesr_comm_init(ctx, int(rank), int(nranks), buf), "nesr_comm_init")
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().nesr_comm_unique_id(buf), "nesr_comm_unique_id")
+        return buf.raw
+
+    @torch.no_grad()
+    def forward_sharded_u8(self, band_u8, frame_hw, tile, tile_pad, through_fp16=False, rank=0):
+        """This rank's rows of a uint8 HWC BGR frame -> (rank 0) the whole upscaled uint8 frame on the device, the tiles of
+        upstream's grid dealt to the ranks of the communicator (nesr_forward_sharded_u8).  Without comm_init: the one-rank case."""
+        self._require_cuda(band_u8)
+        b = band_u8.contiguous()
+        H, W = int(frame_hw[0]), int(frame_hw[1])
+        s = self.out_scale()
+        self.calls += 1
+        with torch.cuda.device(b.device):
+            ctx = self._context(b.device)
+            out = torch.empty((H * s, W * s, 3), dtype=torch.uint8, device=b.device) if rank == 0 else None
+            stream = torch.cuda.current_stream(b.device).cuda_stream
+            _lib.check(_lib.load().nesr_forward_sharded_u8(ctx, ctypes.c_void_p(b.data_ptr()), H, W, int(tile), int(tile_pad), 1 if through_fp16 else 0,
+                                                           ctypes.c_void_p(out.data_ptr() if out is not None else 0), ctypes.c_void_p(stream)),
+                       "nesr_forward_sharded_u8")
+        return out
+
     # ------------------------------------------------------------------ measurement helpers
     def forward_flops(self, n, h, w):
         """Algorithmic FLOPs of one forward on [n, *, h, w]."""

@@ -102,7 +102,8 @@ def _worker(rank, world, port, hw, scale, num_block, out_path, overlap=True):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,hw,scale,overlap", [(2, (64, 48), 2, True), (3, (96, 40), 2, True), (2, (32, 24), 4, True), (2, (64, 48), 2, False)])
+@pytest.mark.parametrize("world,hw,scale,overlap", [(2, (64, 48), 2, True), (3, (96, 40), 2, True), (2, (32, 24), 4, True), (2, (64, 48), 2, False),
+                                                    (4, (160, 40), 2, True), (8, (256, 24), 2, True)])
 def test_banded_equals_untiled_single_process(tmp_path, world, hw, scale, overlap):
     out = str(tmp_path / "banded.npy")
     num_block = 2

@@ -58,6 +58,8 @@ def _worker(rank, world, port, kind, hw, tile, tile_pad, scale, out_path):
     (2, "nearest", (130, 70), 32, 10, 4),
     (3, "nearest", (200, 64), 48, 6, 2),
     (2, "nearest", (64, 64), 0, 10, 2),          # tile=0: one unit, rank 1 only ships rows
+    (4, "nearest", (230, 150), 32, 10, 2),       # 4 ranks: 8 x 5 tiles, ragged last row and column
+    (8, "nearest", (260, 96), 32, 8, 4),         # 8 ranks (the node size of BASELINE.json configs[3]): 9 x 3 tiles, some ranks get three, some four
 ])
 def test_sharded_equals_single_process(tmp_path, world, kind, hw, tile, tile_pad, scale):
     out = str(tmp_path / "res.npy")
@@ -101,6 +103,31 @@ def test_exchange_moves_only_rows_outside_the_band():
             if dd == d:
                 have |= set(range(lo, hi))
         assert have == set(range(n0, n1))
+
+
+@pytest.mark.parametrize("H,W,scale,tile,pad", [(2160, 3840, 2, 512, 10), (1080, 1920, 4, 512, 10), (300, 500, 2, 128, 10), (97, 64, 4, 32, 6),
+                                                 (64, 64, 2, 0, 10)])
+def test_c_abi_plan_is_the_python_plan(H, W, scale, tile, pad):
+    """nesr_shard_plan (what nesr_forward_sharded_u8 runs on, host only) against plan_tiles / exchange_plan for 1 .. 8 ranks."""
+    import ctypes
+    import __graft_entry__ as g
+    g.build()
+    from neural_enhanced_super_resolution_amd import _lib
+    lib = _lib.load()
+    up = RealESRGANer.__new__(RealESRGANer)
+    up.scale, up.tile_size, up.tile_pad, up.pre_pad = scale, tile, pad, 0
+    for world in (1, 2, 3, 4, 8):
+        tiles, owner = sharded.plan_tiles(up, H, W, world)
+        moves = sharded.exchange_plan(tiles, owner, world, H)
+        nt, nm = ctypes.c_int(), ctypes.c_int()
+        t13 = (ctypes.c_int * (13 * 256))()
+        m4 = (ctypes.c_int * (4 * 256))()
+        assert lib.nesr_shard_plan(H, W, scale, tile, pad, world, t13, 256, ctypes.byref(nt), m4, 256, ctypes.byref(nm)) == 0
+        assert nt.value == len(tiles) and nm.value == len(moves)
+        for i, (t, o) in enumerate(zip(tiles, owner)):
+            assert tuple(t13[13 * i:13 * i + 13]) == tuple(t.inp) + tuple(t.out) + tuple(t.crop) + (o,)
+        assert [tuple(m4[4 * i:4 * i + 4]) for i in range(nm.value)] == [tuple(m) for m in moves]
+    assert lib.nesr_shard_plan(0, 8, 2, 4, 1, 1, None, 0, ctypes.byref(nt), None, 0, ctypes.byref(nm)) < 0
 
 
 def test_sharded_rejects_unsupported_padding():
