@@ -257,6 +257,17 @@ int nesr_shard_plan(int H, int W, int scale, int tile, int tile_pad, int nranks,
                     int cap_moves, int* nmoves);
 
 /*
+ * the non-local means inside `cv2.fastNlMeansDenoisingColored(image, None, h, h, 7, 21)` of
+ * SuperResolutionPipeline._preprocess_image (nesr/nesr.py:674), on [C, H, W] u8 planes taken as ONE C-channel image (C = 1: the L
+ * plane, C = 2: the a and b planes).  weights_dev: int32 table over the binned ("almost", >> 6) template distance,
+ * round(M exp(-d / (h^2 C))) with OpenCV's fixed-point M, 0 below M / 1000 (imgproc.nl_means_weights builds it).  The Lab
+ * conversions and CLAHE around it stay torch operations (imgproc.py).  Parity unpinned against cv2 (absent): checked against
+ * oracle/cv2_ref.py, a restatement of OpenCV's invoker.
+ */
+int nesr_nl_means_u8(int device_id, const uint8_t* planes_dev, int C, int H, int W, int template_size, int search_size, const int* weights_dev, int nbins,
+                     uint8_t* out_dev, void* hip_stream);
+
+/*
  * Single-layer entry (test hook for the per-layer parity tests): one 3x3 stride-1 zero-pad-1
  * convolution + bias (+ LeakyReLU(0.2) if lrelu) (+ nearest x2 upsample of the input first if
  * upsample), i.e. torch.nn.Conv2d / F.leaky_relu / F.interpolate as composed in RRDBNet.forward.

@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libnesr_hip.so")
-SOURCES = ["conv3x3_mfma.hip", "conv3x3_bf16.hip", "conv3x3_wino_f32.hip", "conv3x3_f16x2.hip", "rdb_bf16_strip.hip", "pack.hip", "nesr_api.cpp"]
+SOURCES = ["conv3x3_mfma.hip", "conv3x3_bf16.hip", "conv3x3_wino_f32.hip", "conv3x3_f16x2.hip", "rdb_bf16_strip.hip", "imgproc.hip", "pack.hip", "nesr_api.cpp"]
 ARCH = "gfx950"
 
 

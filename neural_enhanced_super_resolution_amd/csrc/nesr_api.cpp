@@ -1212,6 +1212,16 @@ int nesr_paste_tiles_u8(int device_id, const float* tiles_nchw_dev, int n, int H
     return NESR_OK;
 }
 
+int nesr_nl_means_u8(int device_id, const uint8_t* planes_dev, int C, int H, int W, int template_size, int search_size, const int* weights_dev, int nbins,
+                     uint8_t* out_dev, void* stream) {
+    if (!planes_dev || !weights_dev || !out_dev) return fail(NESR_ERR_ARG, "null argument");
+    if (template_size != 7 || search_size != 21) return fail(NESR_ERR_ARG, "nesr_nl_means_u8: template 7 / search 21 (what nesr/nesr.py:674 passes)");
+    if (C < 1 || C > 3 || H < 1 || W < 1 || nbins < 1) return fail(NESR_ERR_ARG, "nesr_nl_means_u8: 1..3 planes, a non-empty image and table");
+    HIP_TRY(hipSetDevice(device_id));
+    HIP_TRY(launch_nl_means(planes_dev, C, H, W, weights_dev, nbins, 6 /* 49 template pixels -> next power of two 64 */, out_dev, static_cast<hipStream_t>(stream)));
+    return NESR_OK;
+}
+
 int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, int H, int W, const float* w_host,
                  const float* b_host, int Cout, int lrelu, int upsample, void* y_dev, void* stream) {
     if (!x_dev || !w_host || !b_host || !y_dev) return fail(NESR_ERR_ARG, "null argument");

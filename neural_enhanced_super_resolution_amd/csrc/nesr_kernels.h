@@ -219,6 +219,9 @@ struct TileIo {
 hipError_t launch_cut_tiles(const TileIo& t, int n, int maxh, int maxw, hipStream_t s);
 hipError_t launch_paste_tiles(const TileIo& t, int n, int maxh, int maxw, hipStream_t s);
 
+// cv2.fastNlMeansDenoising (template 7, search 21) on [C][H][W] u8 planes taken as one C-channel image (imgproc.hip)
+hipError_t launch_nl_means(const uint8_t* src, int C, int H, int W, const int* lut, int nbins, int shift, uint8_t* dst, hipStream_t s);
+
 // feature map (channels [0,c)) -> planar f32 NCHW; used by the single-layer test hook
 hipError_t launch_nhwc_to_nchw(const void* src, int kind /* as PackArgs::bf16 */, Map map, int n, int c, int h, int w, float* dst, hipStream_t s);
 

@@ -288,16 +288,10 @@ def _reflect101_pad(x, r):
     return x[..., _reflect101_index(h, r, x.device), :][..., _reflect101_index(w, r, x.device)]
 
 
-def fast_nl_means_u8(planes, h, template=7, search=21, rows_per_block=0):
-    """cv2.fastNlMeansDenoising on [C, H, W] uint8 planes treated as ONE C-channel image (C = 1: the L plane, C = 2: the ab
-    planes of fastNlMeansDenoisingColored): for every pixel and every offset of the search window the summed squared
-    difference of the template windows (over all channels) is binned (>> 6 for the 7x7 template, as OpenCV's
-    'almost' distance), turned into an integer weight round(M exp(-d / (h^2 C))) (0 below 0.001 M) and the pixels of the
-    search window are averaged with these weights in integer arithmetic (rounded division)."""
-    C, H, W = planes.shape
-    tr, sr = template // 2, search // 2
-    border = tr + sr
-    x = _reflect101_pad(planes.long(), border)                                      # [C, H + 2b, W + 2b]
+def nl_means_weights(C, h, template=7, search=21):
+    """(int64 table of weights over the binned template distance, shift): OpenCV's almost_dist2weight -- round(M exp(-d / (h^2 C)))
+    with the fixed-point multiplier M = INT_MAX // (search^2 * 255), 0 below 0.001 M; bins = distance >> shift, 2^shift the next
+    power of two above template^2."""
     tsq = template * template
     shift = 0
     while (1 << shift) < tsq:
@@ -309,7 +303,42 @@ def fast_nl_means_u8(planes, h, template=7, search=21, rows_per_block=0):
     nbins = ((max_dist * tsq) >> shift) + 1                                          # bins of the 'almost' distance
     d = torch.arange(nbins, dtype=torch.float64) * mult
     wt = torch.round(M * torch.exp(-d / (h * h * C)))
-    wt = torch.where(wt < 0.001 * M, torch.zeros_like(wt), wt).to(torch.int64).to(planes.device)
+    wt = torch.where(wt < 0.001 * M, torch.zeros_like(wt), wt).to(torch.int64)
+    return wt, shift
+
+
+def fast_nl_means_u8(planes, h, template=7, search=21, rows_per_block=0, use_hip=None):
+    """cv2.fastNlMeansDenoising on [C, H, W] uint8 planes treated as ONE C-channel image (C = 1: the L plane, C = 2: the ab
+    planes of fastNlMeansDenoisingColored): for every pixel and every offset of the search window the summed squared
+    difference of the template windows (over all channels) is binned (>> 6 for the 7x7 template, as OpenCV's
+    'almost' distance), turned into an integer weight round(M exp(-d / (h^2 C))) (0 below 0.001 M) and the pixels of the
+    search window are averaged with these weights in integer arithmetic (rounded division).
+
+    On the ROCm device with the reference's window sizes (7, 21: nesr/nesr.py:674) this is one HIP kernel
+    (csrc/imgproc.hip, nesr_nl_means_u8); the torch composition below is kept for other sizes, the CPU and the tests
+    (use_hip=False) -- the two agree bit for bit."""
+    C, H, W = planes.shape
+    wt, shift = nl_means_weights(C, h, template, search)
+    nbins = wt.numel()
+    if use_hip is None:
+        use_hip = planes.device.type == "cuda" and template == 7 and search == 21 and 1 <= C <= 3
+    if use_hip:
+        import ctypes
+        from . import _lib
+        nz = int((wt != 0).sum().item())                                             # the weights fall monotonically to 0: a short table is enough
+        lut = wt[:max(nz + 1, 1)].to(torch.int32).to(planes.device)
+        src = planes.contiguous()
+        out = torch.empty_like(src)
+        index = src.device.index if src.device.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(src.device):
+            stream = torch.cuda.current_stream(src.device).cuda_stream
+            _lib.check(_lib.load().nesr_nl_means_u8(index, ctypes.c_void_p(src.data_ptr()), C, H, W, template, search, ctypes.c_void_p(lut.data_ptr()),
+                                                    lut.numel(), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)), "nesr_nl_means_u8")
+        return out
+    tr, sr = template // 2, search // 2
+    border = tr + sr
+    x = _reflect101_pad(planes.long(), border)                                      # [C, H + 2b, W + 2b]
+    wt = wt.to(planes.device)
     centre = x[:, sr:sr + H + 2 * tr, sr:sr + W + 2 * tr]                            # template-padded view of the image
     acc = torch.zeros((C, H, W), dtype=torch.int64, device=planes.device)
     wsum = torch.zeros((H, W), dtype=torch.int64, device=planes.device)

@@ -30,6 +30,41 @@ def test_imgproc_on_the_device_equals_the_oracle(cuda_device):
     assert dd.max() <= 1 and (dd > 0).mean() < 0.01
 
 
+@pytest.mark.parametrize("C,hw,h", [(1, (37, 53), 5.0), (2, (37, 53), 5.0), (1, (5, 7), 10.0), (2, (64, 64), 3.0), (1, (16, 33), 25.0)])
+def test_nl_means_kernel_is_the_torch_composition_bit_for_bit(cuda_device, C, hw, h):
+    """csrc/imgproc.hip (nesr_nl_means_u8: one launch) against the 441-offset torch composition it replaces, and on the small
+    shapes against the oracle's per-pixel loops (oracle/cv2_ref.py, FastNlMeansDenoisingInvoker restated); nesr/nesr.py:674."""
+    from neural_enhanced_super_resolution_amd import imgproc as P
+    from oracle import cv2_ref as O
+    g = torch.Generator().manual_seed(11)
+    base = torch.randint(0, 256, (C, hw[0] // 4 + 2, hw[1] // 4 + 2), generator=g).float()
+    planes = torch.nn.functional.interpolate(base[None], size=hw, mode="bilinear", align_corners=False)[0]
+    planes = (planes + torch.randint(-6, 7, planes.shape, generator=g)).clamp(0, 255).to(torch.uint8)      # smooth image + noise: weights of every size occur
+    dev = planes.to(cuda_device)
+    got = P.fast_nl_means_u8(dev, h, 7, 21)
+    want = P.fast_nl_means_u8(dev, h, 7, 21, use_hip=False)
+    assert torch.equal(got, want)
+    if h >= 5.0:
+        assert not torch.equal(got, dev)                              # it denoises (with h = 3 every weight but the centre's rounds to 0)
+    if hw[0] * hw[1] <= 600:
+        assert np.array_equal(got.cpu().numpy(), O.fast_nl_means_u8(planes.numpy(), h, 7, 21))
+
+
+def test_nl_means_kernel_time_on_a_large_plane(cuda_device):
+    """2048 x 2048 (the second iteration's input of BASELINE.json configs[4]): seconds as torch operations, milliseconds as a kernel."""
+    import time
+    from neural_enhanced_super_resolution_amd import imgproc as P
+    x = torch.randint(0, 256, (2, 2048, 2048), dtype=torch.uint8, device=cuda_device)
+    P.fast_nl_means_u8(x[:, :64, :64], 5.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    y = P.fast_nl_means_u8(x, 5.0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"nl-means 2 x 2048 x 2048: {dt * 1e3:.1f} ms")
+    assert y.shape == x.shape and dt < 1.0
+
+
 def test_enhance_outscale_on_gpu(cuda_device):
     from neural_enhanced_super_resolution_amd import RealESRGANer, RRDBNet
     from neural_enhanced_super_resolution_amd.synth import synthetic_frame, synthetic_state_dict
