@@ -122,7 +122,7 @@ __device__ __forceinline__ void glds4_s(const char* sbase, unsigned voff, unsign
 }
 // 16-byte write-through store / L1-bypassing load of the edge-column mailboxes
 __device__ __forceinline__ void store16_sc1(char* p, uint4 v) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(__builtin_bit_cast(f32x4, v)) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(f32x4, v)) : "memory");
 }
 __device__ __forceinline__ uint4 load16_sc1_wait(const char* p) {
     f32x4 v;
@@ -135,6 +135,19 @@ __device__ __forceinline__ uint2 pack4_bf16(f32x4 v) {   // plain casts -> v_cvt
 }
 __device__ __forceinline__ f32x4 unpack4_bf16(uint2 u) {
     return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// max(v, 0.2 v), exact; v_max_f32 by hand: fmaxf() first canonicalises its operands (one more VALU instruction per value,
+// in an epilogue that no MFMA covers)
+__device__ __forceinline__ f32x4 lrelu4(f32x4 v) {
+    const f32x2 lo = f32x2{v[0], v[1]} * 0.2f, hi = f32x2{v[2], v[3]} * 0.2f;
+    f32x4 o;
+    asm("v_max_f32 %0, %1, %2" : "=v"(o[0]) : "v"(v[0]), "v"(lo[0]));
+    asm("v_max_f32 %0, %1, %2" : "=v"(o[1]) : "v"(v[1]), "v"(lo[1]));
+    asm("v_max_f32 %0, %1, %2" : "=v"(o[2]) : "v"(v[2]), "v"(hi[0]));
+    asm("v_max_f32 %0, %1, %2" : "=v"(o[3]) : "v"(v[3]), "v"(hi[1]));
+    return o;
 }
 
 struct StripArgs {
@@ -522,10 +535,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                         sl -= sl >= mp.R ? mp.R : 0;
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt) {
-                            f32x4 v = acc[0][r][mt] + bz[mt];
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], v[i] * 0.2f);
-                            uint2 pk = pack4_bf16(v);
+                            uint2 pk = pack4_bf16(lrelu4(acc[0][r][mt] + bz[mt]));
                             pk.x = ok ? pk.x : 0u;
                             pk.y = ok ? pk.y : 0u;
                             *reinterpret_cast<uint2*>(smem + mp.off + sl * ROWB1 + mt * CHB + lane_e) = pk;

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--env", default="")
+    ap.add_argument("--c3", action="store_true", help="the 40 ragged tiles of a 3840x2160 frame cut 512/10 (nesr_forward_ragged, bf16)")
     args = ap.parse_args()
     code = {"f32": 0, "direct": 0, "bf16": 1, "wino": 2, "split": 3}[args.dtype]
     sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=2)
@@ -40,7 +41,27 @@ def main():
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     libs, ctxs = [], []
 
+    hw = None
+    if args.c3:
+        def spans(n):
+            out = []
+            for t in range((n + 511) // 512):
+                a, b = t * 512, min((t + 1) * 512, n)
+                out.append(min(b + 10, n) - max(a - 10, 0))
+            return out
+        sizes = [(hh, ww) for hh in spans(2160) for ww in spans(3840)]
+        args.batch, args.hw = len(sizes), 532
+        hw = (ctypes.c_int * (2 * len(sizes)))(*[v for pr in sizes for v in pr])
+        x = torch.rand(args.batch, 3, args.hw, args.hw, device="cuda")
+        y = [torch.zeros(args.batch, 3, 2 * args.hw, 2 * args.hw, device="cuda") for _ in range(n)]
+
     def run(i):
+        if hw is not None:
+            libs[i].nesr_forward_ragged.argtypes = _lib.SIGNATURES["nesr_forward_ragged"][1]
+            rc = libs[i].nesr_forward_ragged(ctxs[i], ctypes.c_void_p(x.data_ptr()), args.batch, 3, args.hw, args.hw, hw,
+                                             ctypes.c_void_p(y[i].data_ptr()), stream)
+            assert rc == 0, libs[i].nesr_last_error()
+            return
         rc = libs[i].nesr_forward(ctxs[i], ctypes.c_void_p(x.data_ptr()), args.batch, 3, args.hw, args.hw,
                                   ctypes.c_void_p(y[i].data_ptr()), stream)
         assert rc == 0, libs[i].nesr_last_error()
