@@ -36,8 +36,11 @@ typedef struct nesr_ctx nesr_ctx;
  * x = hi + lo * 2^-11 (hi = f16(x), lo = f16((x - hi) * 2^11)), and each product is three f16 MFMAs
  * (hi*hi + hi*lo + lo*hi), see conv3x3_f16x2.hip.  The pair holds 22 significant bits for 6.1e-5 <= |x| <= 65504
  * and an absolute 2^-35 below; a value outside +-65504 or a non-finite one does NOT fit: nesr_finalize_weights
- * rejects such a weight (NESR_ERR_RANGE), and such an input or activation raises the context's sticky range flag --
- * the float output of that forward is then NaN and nesr_check_range / nesr_check_status return NESR_ERR_RANGE.
+ * rejects such a weight (NESR_ERR_RANGE), and such an input or activation raises the context's range flag --
+ * the float output of THAT forward is then NaN and nesr_check_range / nesr_check_status return NESR_ERR_RANGE.  The flag is
+ * scoped to one forward: a caller of nesr_forward that never asks does not get NaN for later, valid frames; the unreported
+ * condition is latched and returned (once) by the next nesr_check_range.  Callers of nesr_forward MUST call nesr_check_range
+ * (or nesr_check_status) before trusting an output.
  * Whole-network max abs error vs an f64 evaluation 3e-6 on the bench weights (plain f32: 1e-6). */
 enum { NESR_DTYPE_F32 = 0, NESR_DTYPE_BF16 = 1, NESR_DTYPE_F32_WINOGRAD = 2, NESR_DTYPE_F32_SPLIT = 3 };
 enum { NESR_ROUND_TRUNC = 0, NESR_ROUND_NEAREST = 1 };
@@ -205,7 +208,8 @@ int nesr_check_status(nesr_ctx* ctx);
 
 /* Range / abort check of the forwards enqueued so far on `hip_stream` (NESR_DTYPE_F32_SPLIT, and contexts whose dense blocks
  * ran as persistent launches; NESR_OK at once otherwise): waits for that stream only, returns NESR_ERR_RANGE if an input or activation did not fit the
- * (hi, lo) pair, and clears the flag.  Where the reference would hand back NaN/Inf pixels
+ * (hi, lo) pair -- in the latest forward, or in an earlier one nobody asked about (the message says which; the latest output is
+ * valid in the second case) -- and clears the flag.  Where the reference would hand back NaN/Inf pixels
  * (`model(img)` on diverged data, nesr/nesr.py:891) this path hands back NaN (float output) plus this error; the
  * Python wrappers call it after every device-to-host copy. */
 int nesr_check_range(nesr_ctx* ctx, void* hip_stream);

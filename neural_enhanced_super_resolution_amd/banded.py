@@ -32,11 +32,15 @@ RRDBNet's; tests drive the same protocol with a CPU engine built from the oracle
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
 from .realesrganer import normalize_u8_on_device
+
+_OVERLAP_CHECKED = set()      # (world size, transport) pairs whose overlapped exchange has been checked against the simple order in this process
 
 APRON = 6        # internal rows of each neighbour a rank carries: >= 5 (an RDB's reach), even (Winograd tile parity)
 
@@ -272,8 +276,23 @@ def enhance_banded(up, band, frame_hw, group=None, gather=True, overlap=True, st
 
     x = normalize_u8_on_device(ext.permute(2, 0, 1).flip(0)).unsqueeze(0)     # BGR->RGB, /255, HWC->NCHW
     if overlap:
-        ex = EdgeExchange(net, rank, world, top, hi - lo, bottom, group, via_cpu, dev, stats)
+        own = {} if stats is None else stats
+        steps0 = own.get("steps", 0)
+        ex = EdgeExchange(net, rank, world, top, hi - lo, bottom, group, via_cpu, dev, own)
         y = forward_banded_overlapped(net, x, top, bottom, ex)
+        key = (world, "gloo" if via_cpu else "device")
+        if world > 1 and key not in _OVERLAP_CHECKED and os.environ.get("NESR_BANDED_SELFCHECK", "1") != "0":
+            # The overlapped protocol (side-stream exchange, persistent staging buffers, row-range conv5 launches) has only run
+            # over gloo and in single-GPU lockstep emulation so far: the first multi-rank frame of a process also goes through the
+            # simple order, and every rank must get bit for bit the same band and the step count of the traffic model.
+            y_ref = forward_banded(net, x, top, bottom, make_exchange(net, rank, world, top, hi - lo, bottom, group, via_cpu))
+            bad = torch.tensor([0 if (torch.equal(y, y_ref) and own.get("steps", 0) - steps0 == 3 * net.num_block + 1) else 1],
+                               dtype=torch.int32, device="cpu" if via_cpu else dev)
+            dist.all_reduce(bad, op=dist.ReduceOp.SUM, group=group)
+            if int(bad.item()):
+                raise RuntimeError(f"enhance_banded: the overlapped exchange disagrees with the simple order on {int(bad.item())} rank(s) "
+                                   f"(this rank: equal={torch.equal(y, y_ref)}, steps={own.get('steps', 0) - steps0}); run with overlap=False")
+            _OVERLAP_CHECKED.add(key)
     else:
         y = forward_banded(net, x, top, bottom, make_exchange(net, rank, world, top, hi - lo, bottom, group, via_cpu))
     q = (y[0].float().clamp_(0, 1).flip(0).permute(1, 2, 0) * 255.0).round().to(torch.uint8).contiguous()   # RGB->BGR, CHW->HWC

@@ -358,6 +358,7 @@ int fw_first(nesr_ctx* c, const FwState& F, const float* x_f32, const uint8_t* x
     p.cp = c->layers[0].cin_p;
     p.bf16 = c->kind();
     p.status = c->dtype == NESR_DTYPE_F32_SPLIT ? c->d_status : nullptr;
+    if (p.status) HIP_TRY(launch_status_latch(c->d_status, s));      // the range word is per forward (nesr_check_range reports a latched one once)
     HIP_TRY(launch_pack_input(p, s));
     ConvArgs a = base_args(c, c->layers[0], F.N, F.h, F.w);
     a.in = ws + F.L.in; a.in_map = F.m_in;
@@ -1015,7 +1016,7 @@ int nesr_check_range(nesr_ctx* c, void* stream) {
     if (c->dtype != NESR_DTYPE_F32_SPLIT && !c->strip_used) return NESR_OK;   // the other forms compute in formats with f32's range
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    HIP_TRY(hipMemcpyAsync(c->h_status, c->d_status, 12, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipMemcpyAsync(c->h_status, c->d_status, 16, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     c->strip_used = false;
     if (c->h_status[2]) {
@@ -1043,10 +1044,20 @@ int nesr_check_range(nesr_ctx* c, void* stream) {
                                   ": its workgroups were not all resident -- another persistent kernel shares the device?); the "
                                   "output of that forward is invalid; this context uses per-layer launches (the same bits) from now on: re-run the frame");
     }
+    if (c->h_status[3] && !*c->h_status) {
+        HIP_TRY(hipMemsetAsync(c->d_status + 3, 0, 4, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        c->h_status[3] = 0;
+        return fail(NESR_ERR_RANGE, "an EARLIER forward on this context (its result was never checked with nesr_check_range) met an input or "
+                                    "activation of the f16-pair fp32 path that was non-finite or exceeded 65504 in magnitude: that forward's "
+                                    "output was NaN / invalid; the latest forward's output is valid");
+    }
     if (*c->h_status) {
         HIP_TRY(hipMemsetAsync(c->d_status, 0, 4, s));   // reported once; the next forward starts clean
+        HIP_TRY(hipMemsetAsync(c->d_status + 3, 0, 4, s));
         HIP_TRY(hipStreamSynchronize(s));
         *c->h_status = 0;
+        c->h_status[3] = 0;
         return fail(NESR_ERR_RANGE, "an input or activation of the f16-pair fp32 path was non-finite or exceeded 65504 in magnitude: "
                                     "the float output of that forward is NaN, an 8-bit output is invalid (use compute_dtype "
                                     "f32-winograd or f32-direct for such data)");

@@ -205,6 +205,7 @@ struct PackArgs {
     unsigned* status;    // as ConvArgs::status (layout 2 only); may be null
 };
 hipError_t launch_pack_input(const PackArgs& a, hipStream_t s);
+hipError_t launch_status_latch(unsigned* status, hipStream_t s);   // range word of an unchecked earlier forward: word 0 -> word 3
 
 // all tiles of a frame at once (pack.hip): u8 HWC frame -> float NCHW tile slots (cut), float NCHW tile outputs -> u8 (paste)
 constexpr int TILE_IO_MAX = 64;

@@ -146,6 +146,17 @@ hipError_t launch_pack_input(const PackArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// The f16-pair path's range word is scoped to one forward: what an earlier forward left in word 0 (nobody asked
+// nesr_check_range about it) moves to word 3 before this forward's first kernel, so conv_last does not poison a valid frame
+// with an older frame's NaN, and the older error is still reported once.
+__global__ void status_latch_kernel(unsigned* st) {
+    if (st[0]) { st[3] = 1u; st[0] = 0u; }
+}
+hipError_t launch_status_latch(unsigned* st, hipStream_t s) {
+    hipLaunchKernelGGL(status_latch_kernel, dim3(1), dim3(1), 0, s, st);
+    return hipGetLastError();
+}
+
 hipError_t launch_nhwc_to_nchw(const void* src, int bf16, Map map, int n, int c, int h, int w, float* dst, hipStream_t s) {
     const size_t total = (size_t)n * c * h * w;
     if (total == 0) return hipSuccess;

@@ -163,6 +163,27 @@ def test_activation_overflow_is_loud(cuda_device):
         up.enhance(synthetic_frame(33, 47, seed=1))          # padded frame: the device-side float path
 
 
+def test_range_flag_is_scoped_to_one_forward(cuda_device):
+    """A caller that uses model(x) directly (as nesr/nesr.py:887-891 does with upsampler.model) and never asks: an out-of-range
+    frame must not turn every later, valid frame of that context into NaN; the unreported condition is latched and the next
+    check reports it once, naming it as an earlier forward's."""
+    from neural_enhanced_super_resolution_amd._lib import NesrRangeError
+    from neural_enhanced_super_resolution_amd.synth import synthetic_state_dict
+    sd = _scaled_trunk(synthetic_state_dict(seed=0, num_in_ch=3, scale=2, num_block=2), 3e5)
+    ours, _ = _nets(sd, 2)
+    x = _x().to(cuda_device)
+    assert torch.isnan(ours(x).cpu()).all()                  # out of range, never checked
+    ok = ours(x * 1e-9).cpu()                                # a valid frame on the same context
+    assert torch.isfinite(ok).all(), "an earlier frame's range condition leaked into a valid frame"
+    with pytest.raises(NesrRangeError, match="EARLIER forward"):
+        ours.check_range()
+    ours.check_range()                                       # reported once
+    assert torch.isnan(ours(x).cpu()).all()
+    with pytest.raises(NesrRangeError) as e:
+        ours.check_range()                                   # the latest forward's own condition
+    assert "EARLIER" not in str(e.value)
+
+
 @pytest.mark.parametrize("bad", [float("nan"), float("inf"), 1e5])
 def test_bad_input_is_loud(cuda_device, bad):
     """The reference propagates a NaN/Inf input to NaN pixels (model(img), nesr/nesr.py:891); so does this path,
