@@ -99,6 +99,7 @@ struct nesr_ctx {
     bool strip_used = false;         // a strip launch went out since the last status check
     unsigned long long strip_timeout_ticks = 20000000ull;   // 200 ms of s_memrealtime: what an inter-workgroup wait of a persistent kernel may take
     int rdb_mode_init = -1, strip_mode_init = -1;
+    int strip_seg = 0;               // NESR_STRIP_SEG: positions per row segment of a strip at most (0: the packer decides, -1: never cut)
     // sharded frames (nesr_comm_init / nesr_forward_sharded_u8): RCCL communicator + scratch
     void* comm = nullptr;            // ncclComm_t
     int comm_rank = 0, comm_nranks = 1;
@@ -290,11 +291,11 @@ int strip_plan_for(nesr_ctx* c, int N, int h, int w, const nesr_ctx::StripPlan**
     }
     nesr_ctx::StripPlan P;
     P.key = key;
-    const StripSchedule S = strip_schedule(N, hw.data(), c->cus);
+    const StripSchedule S = strip_schedule(N, hw.data(), c->cus, c->strip_seg);
     P.makespan = S.makespan;
     if (S.makespan > 0 && S.makespan < 250) {       // tags hold position * 8 + layer below 2048
         P.grid = S.grid; P.smax = S.smax; P.efficiency = S.efficiency;
-        const size_t xb = (size_t)N * S.smax * STRIP_XCH_BYTES;
+        const size_t xb = (size_t)S.nvimg * S.smax * STRIP_XCH_BYTES;
         HIP_TRY(hipMalloc(&P.d_items, S.items.size() * 4));
         HIP_TRY(hipMalloc((void**)&P.d_first, S.wg_first.size() * 4));
         HIP_TRY(hipMalloc((void**)&P.d_xch, xb));
@@ -305,8 +306,8 @@ int strip_plan_for(nesr_ctx* c, int N, int h, int w, const nesr_ctx::StripPlan**
         P.makespan = -1;
     }
     if (getenv("NESR_STRIP_DEBUG"))
-        fprintf(stderr, "[nesr] strip plan: %d images (slot %dx%d): grid %d workgroups, makespan %d positions, efficiency %.3f\n", N, h, w, P.grid,
-                P.makespan, P.efficiency);
+        fprintf(stderr, "[nesr] strip plan: %d images (slot %dx%d) as %d row segments: grid %d workgroups, makespan %d positions, efficiency %.3f\n", N, h, w,
+                S.nvimg, P.grid, P.makespan, P.efficiency);
     c->strip_plans.push_back(std::move(P));
     *out = &c->strip_plans.back();
     return NESR_OK;
@@ -666,6 +667,7 @@ int nesr_create(nesr_ctx** out, int device_id, int conv_first_in_ch, int unshuff
     if (const char* e = getenv("NESR_STRIP")) c->strip_mode = atoi(e);
     c->rdb_mode_init = c->rdb_mode;
     c->strip_mode_init = c->strip_mode;
+    if (const char* e = getenv("NESR_STRIP_SEG")) c->strip_seg = atoi(e);
     if (const char* e = getenv("NESR_FUSED_TIMEOUT_MS")) c->strip_timeout_ticks = (unsigned long long)atoll(e) * 100000ull;
     (void)hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device_id);
     auto add = [&](const std::string& name, int cin, int cout) {

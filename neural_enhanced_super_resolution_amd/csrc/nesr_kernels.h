@@ -143,13 +143,16 @@ hipError_t launch_rdb_f16x2(const RdbLaunch& r, hipStream_t s);
 constexpr int STRIP_BH = 12, STRIP_BW = 16;
 constexpr int STRIP_XCH_BYTES = 2 * 2 * 4 * STRIP_BH * 128;   // edge-column mailboxes of one strip
 struct StripSchedule {
-    std::vector<int> items;      // 4 ints per item: image, strip, image height, image width
+    std::vector<int> items;      // 8 ints per item: image | mailbox group << 16, strip, image height, image width, first position, end
+                                 // position, first output row stored, end row (a row segment of the strip; whole images: 0, npos, 0, h)
     std::vector<int> wg_first;   // [grid + 1]
     int grid = 0, smax = 0, makespan = -1;
+    int nvimg = 0;               // mailbox groups (image segments): the exchange buffer holds nvimg * smax * STRIP_XCH_BYTES
     double efficiency = 0.0;     // strip positions of work / (compute units x makespan)
 };
-// n images of hw[2i] x hw[2i+1] internal pixels -> the packing (makespan < 0: the kernel does not apply)
-StripSchedule strip_schedule(int n, const int* hw, int cus);
+// n images of hw[2i] x hw[2i+1] internal pixels -> the packing (makespan < 0: the kernel does not apply).  seg_len: positions per row
+// segment at most (0: chosen by the packer, < 0: images are never cut)
+StripSchedule strip_schedule(int n, const int* hw, int cus, int seg_len = 0);
 size_t strip_weight_bytes();
 void pack_strip_weights(const float* const w[5], uint16_t* dst);   // conv1..conv5 OIHW f32 of one dense block
 struct StripLaunch {
@@ -159,7 +162,7 @@ struct StripLaunch {
     int H, W;                                     // slot geometry of the batch buffers
     const void* items; const int* wg_first;       // device copies of the schedule
     int grid, smax;
-    void* xch;                                    // n * smax * STRIP_XCH_BYTES
+    void* xch;                                    // nvimg * smax * STRIP_XCH_BYTES
     unsigned epoch;                               // strictly increasing by >= 2048 per launch
     unsigned* abort_flag;
     unsigned long long timeout_ticks;

@@ -212,10 +212,11 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
         }
         bool aborted = false;
         for (int it = it0; it < it1; ++it) {
-            const int4 item = a.items[it];
-            const int img = item.x, s = item.y, h = item.z, w = item.w;
-            const int xs = s * BW, ns = (w + BW - 1) / BW, npos = (h + 4 + BH - 1) / BH;
-            const int slot_id = img * a.smax + s;
+            const int4 item = a.items[2 * it], seg = a.items[2 * it + 1];
+            const int img = item.x & 0xffff, s = item.y, h = item.z, w = item.w;
+            const int pos0 = seg.x, pos1 = seg.y;       // positions of this item (a row segment of the strip: strip_schedule)
+            const int xs = s * BW, ns = (w + BW - 1) / BW;
+            const int slot_id = (item.x >> 16) * a.smax + s;      // mailboxes belong to the (image, segment)
             const bool has_nb = d == 0 ? s > 0 : (d == 1 ? s + 1 < ns : false);
             // x0 loader plan (wave 3): item k = 64 i + lane of a row = chunk k / 36, padded pixel (k % 36) / 2, half k & 1
             unsigned xoff[3];
@@ -247,12 +248,18 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             unsigned long long wbp = WB_INIT;
-            if (d == 3)      // rows 0..12 of x0 (slot of row y at position 0: y mod 18 = y)
-                for (int y = 0; y < 13 && y < h; ++y) x0_row(y, y);
+            for (int k = 0; k < pos0; ++k) wbp = advance_bases(wbp);
+            if (d == 3)      // the x0 rows of the first position: 12 pos0 - 5 .. 12 pos0 + 12 (at position 0: rows 0..12 in slots 0..12)
+                for (int k = 0; k < 18; ++k) {
+                    const int y = BH * pos0 - 5 + k;
+                    int slot = base_of(wbp, 0) + k;
+                    slot -= slot >= 18 ? 18 : 0;
+                    if (y >= 0 && y < h) x0_row(y, slot);
+                }
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            for (int pos = 0; pos < npos; ++pos) {
+            for (int pos = pos0; pos < pos1; ++pos) {
                 int imp_m = 0;          // layer whose edge columns are being imported
                 bool imp_done = true, pending = false;
                 unsigned long long gr[3] = {0ull, 0ull, 0ull};     // the poll in flight: granules lane, 64 + lane, 128 + lane of the mailbox
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                         }
                         wq7 += 3; wq7 -= wq7 >= NWS ? NWS : 0;
                         wq78 += 3; wq78 -= wq78 >= WPER ? WPER : 0;
-                    } else if (pos + 1 < npos) {
+                    } else if (pos + 1 < pos1) {
                         const int tk = idx == 1 ? 0 : idx == 4 ? 1 : idx == 8 ? 2 : idx == 13 ? 3 : idx == 16 ? 4 : -1;
                         if (idx >= 18 && idx < 25) {
                             // the next position's 12 x0 rows over seven steps (2, 2, 2, 2, 2, 1, 1), once conv5 has finished with x0 (its
@@ -469,10 +476,11 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
     };
 
     for (int it = it0; it < it1; ++it) {
-        const int4 item = a.items[it];
-        const int img = item.x, s = item.y, h = item.z, w = item.w;
-        const int xs = s * BW, ns = (w + BW - 1) / BW, npos = (h + 4 + BH - 1) / BH;
-        const int slot_id = img * a.smax + s;
+        const int4 item = a.items[2 * it], seg = a.items[2 * it + 1];
+        const int img = item.x & 0xffff, s = item.y, h = item.z, w = item.w;
+        const int pos0 = seg.x, pos1 = seg.y, row_lo = seg.z, row_hi = seg.w;      // positions run, output rows stored
+        const int xs = s * BW, ns = (w + BW - 1) / BW;
+        const int slot_id = (item.x >> 16) * a.smax + s;
         const bool colok = xs + j16 < w;
         const bool edge = (j16 == 0 && s > 0) || (j16 == BW - 1 && s + 1 < ns);
         char* xch_mine = a.xch + (size_t)slot_id * XCH_STRIP + (j16 == BW - 1 ? 2 * 4 * XCH_LAYER : 0) + g4 * 16 + (3 * wv) * 128;
@@ -483,7 +491,8 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         unsigned long long wbp = WB_INIT;
-        __builtin_amdgcn_s_barrier();      // x0 rows 0..12 and the weight ring's first slots have landed
+        for (int k = 0; k < pos0; ++k) wbp = advance_bases(wbp);
+        __builtin_amdgcn_s_barrier();      // the first position's x0 rows and the weight ring's first slots have landed
         asm volatile("" ::: "memory");
         unsigned ba[5], nba[5];
         baddr_of(wbp, 1, 0, ba);
@@ -492,7 +501,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) load_a(dy, aq);
 
-        for (int pos = 0; pos < npos; ++pos) {
+        for (int pos = pos0; pos < pos1; ++pos) {
             const unsigned tagbase = a.epoch + (unsigned)pos * 8u;
 #if NESR_STRIP_ABL & 256
             const bool stamp_on = it == it0 && pos == 5;
@@ -611,7 +620,9 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     const int y = yw - 4 + r;
-                    const bool valid = colok && y >= 0 && y < h;
+                    // (a row segment stores its own rows only: the rows of its first position above row_lo are the warm-up whose
+                    // x1..x4 inputs it never computed -- the segment above stores them)
+                    const bool valid = colok && y >= row_lo && y < row_hi;
                     const size_t pix = img_px + (size_t)(valid ? y : 0) * a.W + (valid ? xs + j16 : 0);
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2) {
@@ -692,28 +703,30 @@ void pack_strip_weights(const float* const w[5], uint16_t* dst) {
 // the images are packed onto `cus` workgroup time lines: best of a few hundred randomised greedy placements (an image
 // goes to the workgroups that become free earliest and, among those, to the ones that waited least).  Every workgroup's
 // list is in placement order -- one global order of the images -- so the waits between workgroups cannot form a cycle.
-StripSchedule strip_schedule(int n, const int* hw, int cus) {
-    StripSchedule best;
-    best.makespan = -1;
-    struct Unit { int img, ns, npos; };
-    std::vector<Unit> units;
-    long work = 0;
-    int smax = 1;
-    for (int i = 0; i < n; ++i) {
-        Unit u{i, (hw[2 * i + 1] + BW - 1) / BW, (hw[2 * i] + 4 + BH - 1) / BH};
-        if (u.ns > cus) return best;     // an image wider than the device has workgroups: the per-layer kernels take it
-        smax = std::max(smax, u.ns);
-        work += (long)u.ns * u.npos;
-        units.push_back(u);
-    }
+//
+// A batch with fewer strips than the device has compute units (one rank's share of a sharded frame, a small frame) would
+// leave most of them idle for the 23 positions of a tile.  An image may therefore be cut into ROW SEGMENTS that run as
+// independent units: the segment that stores the rows of positions [a, b) of the image's own position grid starts one
+// position early (position a - 1 is its warm-up: layer m there finds no rows of x_{m-1} from a position before, so the
+// first 4 output rows it could store are wrong and are left to the segment above -- from row 12 (a - 1) + 4 on every value
+// has exactly the operands of the unsegmented sweep, in the same order: the same bits).  One more position per extra
+// segment, `seg_len` = most positions of the image's grid per segment (0: the packer tries several and keeps the
+// shortest makespan; < 0: never cut).
+namespace {
+struct Unit { int img, vimg, ns, pos0, pos1, row_lo, row_hi; };
+
+bool pack_units(const std::vector<Unit>& units, const int* hw, int cus, int trials, StripSchedule& best) {
+    const int n = (int)units.size();
     std::mt19937 rng(12345);
     std::vector<int> order(n), load(cus), idx(cus);
-    for (int trial = 0; trial < 300; ++trial) {
+    bool improved = false;
+    for (int trial = 0; trial < trials; ++trial) {
         for (int i = 0; i < n; ++i) order[i] = i;
-        // tallest first; within one height a random order of the widths (trial 0: widest first)
+        // longest first; within one length a random order of the widths (trial 0: widest first)
         if (trial) std::shuffle(order.begin(), order.end(), rng);
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
-            if (units[x].npos != units[y].npos) return units[x].npos > units[y].npos;
+            const int lx = units[x].pos1 - units[x].pos0, ly = units[y].pos1 - units[y].pos0;
+            if (lx != ly) return lx > ly;
             return trial == 0 && units[x].ns > units[y].ns;
         });
         std::fill(load.begin(), load.end(), 0);
@@ -728,30 +741,85 @@ StripSchedule strip_schedule(int n, const int* hw, int cus) {
             // of the cnt candidates take the ns that became free last (least idle time thrown away)
             for (int k = 0; k < u.ns; ++k) {
                 const int g = idx[cnt - u.ns + k];
-                load[g] = start + u.npos;
-                lists[g].push_back(u.img * 4096 + k);
+                load[g] = start + (u.pos1 - u.pos0);
+                lists[g].push_back(order[oi] * 4096 + k);
             }
         }
         const int mk = *std::max_element(load.begin(), load.end());
         if (best.makespan < 0 || mk < best.makespan) {
+            improved = true;
             best.makespan = mk;
             best.items.clear();
             best.wg_first.clear();
             int used = 0;
             for (int g = 0; g < cus; ++g) {
                 if (lists[g].empty()) continue;
-                best.wg_first.push_back((int)best.items.size() / 4);
+                best.wg_first.push_back((int)best.items.size() / 8);
                 for (int code : lists[g]) {
-                    const int img = code / 4096, s = code % 4096;
-                    best.items.push_back(img);
-                    best.items.push_back(s);
-                    best.items.push_back(hw[2 * img]);
-                    best.items.push_back(hw[2 * img + 1]);
+                    const Unit& u = units[code / 4096];
+                    const int s = code % 4096;
+                    const int it[8] = {u.img | (u.vimg << 16), s, hw[2 * u.img], hw[2 * u.img + 1], u.pos0, u.pos1, u.row_lo, u.row_hi};
+                    best.items.insert(best.items.end(), it, it + 8);
                 }
                 ++used;
             }
-            best.wg_first.push_back((int)best.items.size() / 4);
+            best.wg_first.push_back((int)best.items.size() / 8);
             best.grid = used;
+            best.nvimg = n;
+        }
+    }
+    return improved;
+}
+}  // namespace
+
+StripSchedule strip_schedule(int n, const int* hw, int cus, int seg_len) {
+    StripSchedule best;
+    best.makespan = -1;
+    long work = 0;
+    int smax = 1, pmax = 1;
+    for (int i = 0; i < n; ++i) {
+        const int ns = (hw[2 * i + 1] + BW - 1) / BW, npos = (hw[2 * i] + 4 + BH - 1) / BH;
+        if (ns > cus) return best;     // an image wider than the device has workgroups: the per-layer kernels take it
+        smax = std::max(smax, ns);
+        pmax = std::max(pmax, npos);
+        work += (long)ns * npos;
+    }
+    auto units_for = [&](int L) {      // L = positions of an image's grid per segment at most (0: whole images)
+        std::vector<Unit> units;
+        for (int i = 0; i < n; ++i) {
+            const int h = hw[2 * i], ns = (hw[2 * i + 1] + BW - 1) / BW, npos = (h + 4 + BH - 1) / BH;
+            const int k = L > 0 ? (npos + L - 1) / L : 1;
+            int a = 0;
+            for (int j = 0; j < k; ++j) {
+                const int b = a + npos / k + (j < npos % k ? 1 : 0);
+                Unit u;
+                u.img = i; u.vimg = (int)units.size(); u.ns = ns;
+                u.pos0 = a > 0 ? a - 1 : 0; u.pos1 = b;
+                u.row_lo = a > 0 ? BH * a - 4 : 0;
+                u.row_hi = b < npos ? BH * b - 4 : h;
+                if (u.row_hi > h) u.row_hi = h;
+                if (u.row_lo < u.row_hi || k == 1) units.push_back(u);
+                a = b;
+            }
+        }
+        return units;
+    };
+    pack_units(units_for(0), hw, cus, 300, best);
+    if (seg_len > 0) {
+        StripSchedule cut;
+        cut.makespan = -1;
+        const std::vector<Unit> u = units_for(seg_len);
+        if (u.size() < 32768 && pack_units(u, hw, cus, 100, cut)) best = cut;
+    } else if (seg_len == 0 && pmax > 4) {
+        // cutting pays when the whole images leave compute units idle; the candidates that can shorten the sweep of the
+        // tallest image: 2, 3, 4 ... segments of it
+        for (int k = 2; k <= 8 && best.makespan > (int)((work + cus - 1) / cus) + 1; ++k) {
+            const int L = (pmax + k - 1) / k;
+            if (L < 3) break;
+            const std::vector<Unit> u = units_for(L);
+            if (u.size() >= 32768) break;
+            StripSchedule cut = best;      // (kept unless a shorter one is found: pack_units only replaces on improvement)
+            if (pack_units(u, hw, cus, 60, cut)) best = cut;
         }
     }
     best.smax = smax;

@@ -23,10 +23,12 @@ def _psnr(a, b):
     return float(10.0 * torch.log10(1.0 / ((a.double() - b.double()) ** 2).mean()))
 
 
-def _net(scale, strip, sd):
+def _net(scale, strip, sd, seg=None):
     from neural_enhanced_super_resolution_amd import RRDBNet
-    old = os.environ.get("NESR_STRIP")
+    old, old_seg = os.environ.get("NESR_STRIP"), os.environ.get("NESR_STRIP_SEG")
     os.environ["NESR_STRIP"] = strip          # read when the device context is created (first forward)
+    if seg is not None:
+        os.environ["NESR_STRIP_SEG"] = seg
     try:
         net = RRDBNet(3, 3, scale=scale, num_block=NB, compute_dtype="bf16")
         net.load_state_dict(sd)
@@ -34,10 +36,11 @@ def _net(scale, strip, sd):
         net.size_independent = True
         net(torch.zeros(1, 3, 4 * (4 // scale), 4 * (4 // scale), device="cuda:0"))      # creates the context under the switch
     finally:
-        if old is None:
-            os.environ.pop("NESR_STRIP", None)
-        else:
-            os.environ["NESR_STRIP"] = old
+        for k, v in (("NESR_STRIP", old), ("NESR_STRIP_SEG", old_seg)):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     return net
 
 
@@ -147,3 +150,26 @@ def test_strip_full_ragged_batch_of_64(cuda_device):
             os.environ.pop("NESR_STRIP", None)
         else:
             os.environ["NESR_STRIP"] = old
+
+
+@pytest.mark.parametrize("scale", [2, 4])
+def test_row_segments_give_the_bits_of_the_whole_sweep(cuda_device, scale):
+    """A strip cut into row segments (what the packer does when a batch has fewer strips than the device has compute units:
+    one rank's share of a sharded frame, a small frame) stores, row for row, the bits of the uncut sweep: every segment
+    starts one position early and leaves the rows of that warm-up position to the segment above."""
+    from neural_enhanced_super_resolution_amd.synth import synthetic_state_dict
+    sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=scale, num_block=NB)
+    u = 4 // scale if scale in (2, 1) else 1
+    u = 2 if scale == 2 else 1
+    g = torch.Generator().manual_seed(21)
+    shapes = [(266 * u, 40 * u), (130 * u, 72 * u), (61 * u, 33 * u), (25 * u, 16 * u), (13 * u, 50 * u)]      # trunk heights 266 (23 positions) ... 13 (2)
+    imgs = [torch.rand(1, 3, h, w, generator=g) for h, w in shapes]
+    whole = _ragged(_net(scale, "1", sd, seg="-1"), imgs)
+    for seg in ("2", "3", "7", "0"):          # at most 2 / 3 / 7 positions per segment; the packer's own choice
+        net = _net(scale, "1", sd, seg=seg)
+        net.set_kernel_timing("cuda:0", True)
+        net.kernel_time()
+        cut = _ragged(net, imgs)
+        assert net.kernel_time()[1] == 3 * NB
+        for j in range(len(imgs)):
+            assert torch.equal(cut[j], whole[j]), (seg, shapes[j], (cut[j] - whole[j]).abs().max().item())

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--env", default="")
     ap.add_argument("--c3", action="store_true", help="the 40 ragged tiles of a 3840x2160 frame cut 512/10 (nesr_forward_ragged, bf16)")
+    ap.add_argument("--share", type=int, default=1, help="with --c3: only every share-th tile (what one of `share` ranks of a sharded frame evaluates)")
     args = ap.parse_args()
     code = {"f32": 0, "direct": 0, "bf16": 1, "wino": 2, "split": 3}[args.dtype]
     sd = synthetic_state_dict(seed=0, num_in_ch=3, scale=2)
@@ -49,7 +50,7 @@ def main():
                 a, b = t * 512, min((t + 1) * 512, n)
                 out.append(min(b + 10, n) - max(a - 10, 0))
             return out
-        sizes = [(hh, ww) for hh in spans(2160) for ww in spans(3840)]
+        sizes = [(hh, ww) for hh in spans(2160) for ww in spans(3840)][::args.share]
         args.batch, args.hw = len(sizes), 532
         hw = (ctypes.c_int * (2 * len(sizes)))(*[v for pr in sizes for v in pr])
         x = torch.rand(args.batch, 3, args.hw, args.hw, device="cuda")
