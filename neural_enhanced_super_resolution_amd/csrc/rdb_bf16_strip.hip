@@ -784,11 +784,12 @@ StripSchedule strip_schedule(int n, const int* hw, int cus, int seg_len) {
         pmax = std::max(pmax, npos);
         work += (long)ns * npos;
     }
-    auto units_for = [&](int L) {      // L = positions of an image's grid per segment at most (0: whole images)
+    // images of at most `thr` positions are cut into segments of at most L positions of their grid (L = 0: not cut)
+    auto units_for = [&](int L, int thr) {
         std::vector<Unit> units;
         for (int i = 0; i < n; ++i) {
             const int h = hw[2 * i], ns = (hw[2 * i + 1] + BW - 1) / BW, npos = (h + 4 + BH - 1) / BH;
-            const int k = L > 0 ? (npos + L - 1) / L : 1;
+            const int k = L > 0 && npos <= thr ? (npos + L - 1) / L : 1;
             int a = 0;
             for (int j = 0; j < k; ++j) {
                 const int b = a + npos / k + (j < npos % k ? 1 : 0);
@@ -804,23 +805,32 @@ StripSchedule strip_schedule(int n, const int* hw, int cus, int seg_len) {
         }
         return units;
     };
-    pack_units(units_for(0), hw, cus, 300, best);
+    pack_units(units_for(0, 0), hw, cus, 300, best);
+    const int bound = (int)((work + cus - 1) / cus);
+    auto consider = [&](int L, int thr, int trials) {
+        if (L < 2 || best.makespan <= bound) return;
+        const std::vector<Unit> u = units_for(L, thr);
+        if (u.size() >= 32768) return;
+        StripSchedule cut = best;      // pack_units replaces it only by a shorter makespan
+        if (pack_units(u, hw, cus, trials, cut)) best = cut;
+    };
     if (seg_len > 0) {
         StripSchedule cut;
         cut.makespan = -1;
-        const std::vector<Unit> u = units_for(seg_len);
+        const std::vector<Unit> u = units_for(seg_len, pmax);
         if (u.size() < 32768 && pack_units(u, hw, cus, 100, cut)) best = cut;
     } else if (seg_len == 0 && pmax > 4) {
-        // cutting pays when the whole images leave compute units idle; the candidates that can shorten the sweep of the
-        // tallest image: 2, 3, 4 ... segments of it
-        for (int k = 2; k <= 8 && best.makespan > (int)((work + cus - 1) / cus) + 1; ++k) {
-            const int L = (pmax + k - 1) / k;
-            if (L < 3) break;
-            const std::vector<Unit> u = units_for(L);
-            if (u.size() >= 32768) break;
-            StripSchedule cut = best;      // (kept unless a shorter one is found: pack_units only replaces on improvement)
-            if (pack_units(u, hw, cus, 60, cut)) best = cut;
-        }
+        // Cutting pays when whole images leave compute units idle.  (a) every image, in 2, 3, ... segments of the tallest
+        // (batches with fewer strips than compute units); (b) only the images of at most p positions, halved or cut in three
+        // (a full 4K frame: its 512 tall strips fill the device twice, the 128 strips of the short bottom tile row would
+        // keep half of it busy for 6 more positions -- halved they are 3 or 4 positions on all of it: 52 -> 50).
+        for (int k = 2; k <= 8; ++k) consider((pmax + k - 1) / k, pmax, 60);
+        std::vector<int> classes;
+        for (int i = 0; i < n; ++i) classes.push_back((hw[2 * i] + 4 + BH - 1) / BH);
+        std::sort(classes.begin(), classes.end());
+        classes.erase(std::unique(classes.begin(), classes.end()), classes.end());
+        for (size_t ci = 0; ci + 1 < classes.size() && ci < 6; ++ci)
+            for (int k = 2; k <= 3; ++k) consider((classes[ci] + k - 1) / k, classes[ci], 150);
     }
     best.smax = smax;
     best.efficiency = best.makespan > 0 ? (double)work / ((double)cus * best.makespan) : 0.0;
