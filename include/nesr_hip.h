@@ -115,9 +115,12 @@ int nesr_forward_u8(nesr_ctx* ctx, const uint8_t* in_hwc_dev, int H, int W, uint
  */
 int nesr_forward_ragged(nesr_ctx* ctx, const void* x_dev, int N, int C, int H, int W, const int* hw, void* y_dev, void* stream);
 
-/* Choose kernels by arithmetic only, never by image size (bf16: the large-tile kernel also for small images), so that an
- * image's values are the same bits alone, in an equal-shape batch and in a ragged batch.  RealESRGANer sets it for a
- * tiling wrapper.  Slower for single small frames; off by default. */
+/* Choose kernels by arithmetic only, never by image size or batch composition, so that an image's values are the same bits
+ * alone, in an equal-shape batch and in a ragged batch -- and on any rank of a sharded frame, whatever its share.  bf16: the dense
+ * blocks always run as the LDS-resident kernel (rdb_bf16_strip_kernel; a batch too small to fill the device is cut into row
+ * segments, which does not change a bit), the other layers as the large-tile kernel also for small images.  RealESRGANer sets it
+ * for a tiling wrapper.  Off by default: a plain context picks whichever form is faster for the batch at hand (the two bf16
+ * forms agree to bf16 resolution, not bit for bit). */
 int nesr_set_size_independent(nesr_ctx* ctx, int on);
 
 /* Device bytes of activation workspace forward() needs for a batch of N frames of H x W input. */
