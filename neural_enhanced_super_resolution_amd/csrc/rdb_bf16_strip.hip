@@ -494,6 +494,11 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
         for (int k = 0; k < pos0; ++k) wbp = advance_bases(wbp);
         __builtin_amdgcn_s_barrier();      // the first position's x0 rows and the weight ring's first slots have landed
         asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)      // conv1's sums start from its bias (the table is in LDS since the first barrier)
+                acc[0][r][mt] = *reinterpret_cast<const f32x4*>(smem + BIASO + (16 * mt + 4 * g4) * 4);
         unsigned ba[5], nba[5];
         baddr_of(wbp, 1, 0, ba);
 #pragma unroll
@@ -511,6 +516,8 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
             const unsigned long long wbn = advance_bases(wbp);
             const int yw = BH * pos + 3 * wv;       // this wave's first row of layer 1 at this position
             // ---- conv1..conv4 (the layer number is a compile-time constant of each copy)
+            // bias vector (floats boff + 16 mt + 4 g4 .. + 3 of the table) for this lane's four couts
+            auto bias4 = [&](int boff, int mt) { return *reinterpret_cast<const f32x4*>(smem + BIASO + (boff + 16 * mt + 4 * g4) * 4); };
             auto layer = [&](auto Mc) {
                 constexpr int m = decltype(Mc)::value;
                 for (int p = 0; p <= m; ++p) {
@@ -530,9 +537,9 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                 }
                 if (!(NESR_STRIP_ABL & 8)) {
                     // ---- x_m = lrelu(acc + bias): into this strip's window, edge columns also to the neighbours
+                    // (the sums started from the bias: a bias read here would stand, with its LDS round trip, between the last
+                    // MFMA and the first store)
                     const MapP mp = map_of(m);
-                    const char* bsrc = smem + BIASO + ((m - 1) * 32 + 4 * g4) * 4;
-                    const f32x4 bz[2] = {*reinterpret_cast<const f32x4*>(bsrc), *reinterpret_cast<const f32x4*>(bsrc + 64)};
                     const unsigned tag = tagbase + (unsigned)m;
                     char* xdst = xch_mine + ((size_t)(pos & 1) * 4 + (m - 1)) * XCH_LAYER;
                     const int bm = base_of(wbp, m);
@@ -544,21 +551,21 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                         sl -= sl >= mp.R ? mp.R : 0;
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt) {
-                            uint2 pk = pack4_bf16(lrelu4(acc[0][r][mt] + bz[mt]));
+                            uint2 pk = pack4_bf16(lrelu4(acc[0][r][mt]));
                             pk.x = ok ? pk.x : 0u;
                             pk.y = ok ? pk.y : 0u;
                             *reinterpret_cast<uint2*>(smem + mp.off + sl * ROWB1 + mt * CHB + lane_e) = pk;
                             if (edge) store16_sc1(xdst + r * 128 + mt * 64, uint4{pk.x, tag, pk.y, tag});
-                            acc[0][r][mt] = zero4;
+                            if (m < 4) acc[0][r][mt] = bias4(m * 32, mt);      // the next layer's sums start from its bias
                         }
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (m < 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     SSTAMP(wv, sidx - 1, 3);
                 } else {
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) { asm volatile("" ::"v"(acc[0][r][mt])); acc[0][r][mt] = zero4; }
+                        for (int mt = 0; mt < 2; ++mt) { asm volatile("" ::"v"(acc[0][r][mt])); acc[0][r][mt] = bias4(m < 4 ? m * 32 : 0, mt); }
                 }
             };
             layer(std::integral_constant<int, 1>{});
@@ -576,9 +583,13 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                 for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
-                        acc[c2][r][mt] = unpack4_bf16(*reinterpret_cast<const uint2*>(smem + sl * ROWB0 + (2 * c2 + mt) * CHB + lane_e)) * inv_s1;
+                    {
+                        const f32x4 u = unpack4_bf16(*reinterpret_cast<const uint2*>(smem + sl * ROWB0 + (2 * c2 + mt) * CHB + lane_e)), bz = bias4(128 + 32 * c2, mt);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) acc[c2][r][mt][i] = fmaf(u[i], inv_s1, bz[i]);
+                    }
             }
-            uint2 res2v[2][3][2];
+            uint4 res2q[2][3];      // second residual, 16 bytes per lane in the regrouped layout of the output stores (below)
             for (int p = 0; p < 6; ++p) {
                 SSTAMP(wv, sidx, 0);
                 __builtin_amdgcn_s_barrier();
@@ -599,9 +610,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                             const int y = yw - 4 + r;
                             const bool valid = colok && y >= 0 && y < h;
                             const size_t pix = img_px + (size_t)(valid ? y : 0) * a.W + (valid ? xs + j16 : 0);
-#pragma unroll
-                            for (int mt = 0; mt < 2; ++mt)
-                                res2v[c2][r][mt] = *reinterpret_cast<const uint2*>(a.res2 + (size_t)(2 * c2 + mt) * a.chunk_bytes + pix * 32 + g4 * 8);
+                            res2q[c2][r] = *reinterpret_cast<const uint4*>(a.res2 + (size_t)(2 * c2 + (g4 & 1)) * a.chunk_bytes + pix * 32 + (g4 >> 1) * 16);
                         }
                 }
                 SSTAMP(wv, sidx, 0);
@@ -626,17 +635,32 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                     const size_t pix = img_px + (size_t)(valid ? y : 0) * a.W + (valid ? xs + j16 : 0);
 #pragma unroll
                     for (int c2 = 0; c2 < 2; ++c2) {
-                        const char* bsrc = smem + BIASO + (128 + 32 * c2 + 4 * g4) * 4;
+                        // A lane holds 4 couts (8 bytes) of chunk 2 c2 and 4 of chunk 2 c2 + 1.  One v_permlane16_swap per register
+                        // (odd 16-lane rows of the first <-> even rows of the second) leaves it with 8 consecutive couts of ONE chunk --
+                        // chunk 2 c2 + (g4 & 1), byte 16 (g4 >> 1) of the pixel's 32 -- so that the block's output leaves in 6 store
+                        // instructions per wave and position instead of 12, and the second residual arrives in 6 loads (the swap is its
+                        // own inverse).  A vector-memory instruction issued by an MFMA wave beside the DMA waves' bursts costs that
+                        // wave a few hundred cycles: these are the only ones it has.
+                        f32x4 v[2] = {acc[c2][r][0] * a.s1, acc[c2][r][1] * a.s1};
+                        if (a.res2) {
+                            const uint4 q = res2q[c2][r];
+                            const auto sx = __builtin_amdgcn_permlane16_swap(q.x, q.z, false, false);
+                            const auto sy = __builtin_amdgcn_permlane16_swap(q.y, q.w, false, false);
+                            const f32x4 q0 = unpack4_bf16(uint2{sx[0], sy[0]}), q1 = unpack4_bf16(uint2{sx[1], sy[1]});
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) {
-                            f32x4 v = (acc[c2][r][mt] + *reinterpret_cast<const f32x4*>(bsrc + 64 * mt)) * a.s1;
-                            if (a.res2) {
-                                const f32x4 q2 = unpack4_bf16(res2v[c2][r][mt]);
-#pragma unroll
-                                for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(__fmul_rn(v[i], a.s2), q2[i]);
+                            for (int i = 0; i < 4; ++i) {
+                                v[0][i] = __fadd_rn(__fmul_rn(v[0][i], a.s2), q0[i]);
+                                v[1][i] = __fadd_rn(__fmul_rn(v[1][i], a.s2), q1[i]);
                             }
-                            if (valid) *reinterpret_cast<uint2*>(a.out + (size_t)(2 * c2 + mt) * a.chunk_bytes + pix * 32 + g4 * 8) = pack4_bf16(v);
-                            acc[c2][r][mt] = zero4;
+                        }
+                        const uint2 p0 = pack4_bf16(v[0]), p1 = pack4_bf16(v[1]);
+                        const auto ox = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+                        const auto oy = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
+                        if (valid)
+                            *reinterpret_cast<uint4*>(a.out + (size_t)(2 * c2 + (g4 & 1)) * a.chunk_bytes + pix * 32 + (g4 >> 1) * 16) = uint4{ox[0], oy[0], ox[1], oy[1]};
+                        if (c2 == 0) {
+                            acc[0][r][0] = bias4(0, 0);      // conv1 of the next position
+                            acc[0][r][1] = bias4(0, 1);
                         }
                     }
                 }
@@ -646,7 +670,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
 #pragma unroll
                     for (int r = 0; r < 3; ++r)
 #pragma unroll
-                        for (int mt = 0; mt < 2; ++mt) { asm volatile("" ::"v"(acc[c2][r][mt])); acc[c2][r][mt] = zero4; }
+                        for (int mt = 0; mt < 2; ++mt) { asm volatile("" ::"v"(acc[c2][r][mt])); acc[c2][r][mt] = bias4(0, mt); }
             }
             SSTAMP(wv, 25, 3);
 #if NESR_STRIP_ABL & 256
