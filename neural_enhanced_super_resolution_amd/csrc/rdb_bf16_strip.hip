@@ -108,6 +108,30 @@ __device__ __forceinline__ void glds16_s(const char* sbase, unsigned voff, unsig
         : "v"(voff), "s"(sbase), "s"(lds_dst)
         : "memory");
 }
+// six consecutive 1-KiB pieces (one 6-KiB weight slot) by ONE wave: the instruction's immediate offset moves the global and the
+// LDS address alike, so M0 and the scalar base are set up twice per slot instead of once per piece (the scalar address
+// arithmetic of six separate pieces was ~100 of the ~125 cycles a piece cost the issuing wave)
+__device__ __forceinline__ void glds16_slot6_s(const char* sbase, unsigned voff, unsigned lds_dst) {
+    unsigned keep;
+    const char* sbase2 = sbase + 4096;
+    const unsigned lds2 = lds_dst + 4096;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+        "s_mov_b32 m0, %5\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %4\n\t"
+        "global_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst), "s"(sbase2), "s"(lds2)
+        : "memory");
+}
 __device__ __forceinline__ void glds4_s(const char* sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
     asm volatile(
@@ -288,11 +312,21 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                     const unsigned tag = a.epoch + (unsigned)pos * 8u + (unsigned)imp_m;
                     const unsigned long long* src = reinterpret_cast<const unsigned long long*>(
                         a.xch + ((((size_t)(slot_id + (d ? 1 : -1)) * 2 + (1 - d)) * 2 + (pos & 1)) * 4 + (imp_m > 0 ? imp_m - 1 : 0)) * XCH_LAYER) + lane;
+                    // The three loads of a poll are hand-written (`global_load_dwordx2 ... sc1` = the relaxed agent-scope load) and waited
+                    // for by COUNT: the compiler would put `s_waitcnt vmcnt(0)` in front of the first use of a load it knows about, and
+                    // that wait would also cover this wave's six weight pieces of the step (or, placed in front of them, hold them back
+                    // for the rest of the poll's ~2500-cycle round trip -- measured: that was most of the barrier waits of a position).
                     auto poll_issue = [&]() {
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) gr[j] = __hip_atomic_load(src + 64 * j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        asm volatile("global_load_dwordx2 %0, %3, off sc1\n\tglobal_load_dwordx2 %1, %4, off sc1\n\tglobal_load_dwordx2 %2, %5, off sc1"
+                                     : "=&v"(gr[0]), "=&v"(gr[1]), "=&v"(gr[2])
+                                     : "v"(src), "v"(src + 64), "v"(src + 128)
+                                     : "memory");
                         pending = true;
                     };
+                    auto poll_landed_behind_weights = [&]() {      // the poll is older than the six weight pieces just issued
+                        asm volatile("s_waitcnt vmcnt(6)" : "+v"(gr[0]), "+v"(gr[1]), "+v"(gr[2])::"memory");
+                    };
+                    auto poll_landed = [&]() { asm volatile("s_waitcnt vmcnt(0)" : "+v"(gr[0]), "+v"(gr[1]), "+v"(gr[2])::"memory"); };
                     auto poll_take = [&]() -> bool {      // the poll in flight: complete? then into the window's halo column
                         const bool ok = aborted || ((unsigned)(gr[0] >> 32) == tag && (unsigned)(gr[1] >> 32) == tag && (unsigned)(gr[2] >> 32) == tag);
                         pending = false;
@@ -311,17 +345,14 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                         imp_done = true;
                         return true;
                     };
-                    if (polling && pending) poll_take();
                     if (d < 3) {
-                        // weights of q = 3 g + 4, + 5, + 6 into the slots step g - 1 has finished with
-#pragma unroll
-                        for (int t0 = 0; t0 < 18; t0 += 3) {
-                            const int t = t0 + d;
-                            const int which = t / 6, kb = t - 6 * which;
-                            int q7 = wq7 + which, q78 = wq78 + which;
+                        // weights of q = 3 g + 4, + 5, + 6 into the slots step g - 1 has finished with: wave d the whole slot q + d
+                        {
+                            int q7 = wq7 + d, q78 = wq78 + d;
                             q7 -= q7 >= NWS ? NWS : 0;
                             q78 -= q78 >= WPER ? WPER : 0;
-                            weight_task(q7, q78, kb);
+                            if (!(NESR_STRIP_ABL & 4))
+                                glds16_slot6_s(a.wstream + (size_t)q78 * WSLOT, (unsigned)lane * 16u, __builtin_amdgcn_readfirstlane(lds0 + WRING + q7 * WSLOT));
                         }
                         wq7 += 3; wq7 -= wq7 >= NWS ? NWS : 0;
                         wq78 += 3; wq78 -= wq78 >= WPER ? WPER : 0;
@@ -357,14 +388,19 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                         }
                     }
                     SSTAMP(MW + d, idx, 3);
+                    if (polling && pending) {      // last step's poll, looked at behind this step's weight pieces
+                        if (NESR_STRIP_ABL & 4) poll_landed(); else poll_landed_behind_weights();
+                        poll_take();
+                    }
                     if (polling && !imp_done) {
                         const int m = imp_m;
                         const bool block = idx == (m == 1 ? 3 : m == 2 ? 7 : m == 3 ? 12 : 23);
                         unsigned long long t_start = 0;
                         for (unsigned spin = 0;; ++spin) {
-                            if (pending && poll_take()) break;
                             poll_issue();
                             if (!block) break;
+                            poll_landed();
+                            if (poll_take()) break;
                             // bounded: a neighbour that never publishes (its workgroup not resident) ends in an abort word
                             const unsigned long long now = __builtin_amdgcn_s_memrealtime();
                             if (spin == 0) t_start = now;
