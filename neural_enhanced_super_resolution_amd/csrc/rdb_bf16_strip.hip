@@ -132,6 +132,31 @@ __device__ __forceinline__ void glds16_slot6_s(const char* sbase, unsigned voff,
         : "v"(voff), "s"(sbase), "s"(lds_dst), "s"(sbase2), "s"(lds2)
         : "memory");
 }
+// one row of the x0 window = three pieces with per-piece lane masks (columns outside the image, lanes past the row's 2304
+// bytes): M0 set up once, the pieces' LDS offsets as immediates (the same immediate moves the global address: taken out of
+// the scalar bases), EXEC narrowed per piece
+__device__ __forceinline__ void glds16_row3_s(const char* sbase, unsigned v0, unsigned v1, unsigned v2, unsigned lds_dst,
+                                              unsigned long long m0_, unsigned long long m1_, unsigned long long m2_) {
+    unsigned keep;
+    unsigned long long save;
+    const char* sb1 = sbase - 1024;
+    const char* sb2 = sbase - 2048;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b64 %1, exec\n\t"
+        "s_mov_b32 m0, %6\n\t"
+        "s_and_b64 exec, %1, %9\n\t"
+        "global_load_lds_dwordx4 %2, %5\n\t"
+        "s_and_b64 exec, %1, %10\n\t"
+        "global_load_lds_dwordx4 %3, %7 offset:1024\n\t"
+        "s_and_b64 exec, %1, %11\n\t"
+        "global_load_lds_dwordx4 %4, %8 offset:2048\n\t"
+        "s_mov_b64 exec, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep), "=&s"(save)
+        : "v"(v0), "v"(v1), "v"(v2), "s"(sbase), "s"(lds_dst), "s"(sb1), "s"(sb2), "s"(m0_), "s"(m1_), "s"(m2_)
+        : "memory");
+}
 __device__ __forceinline__ void glds4_s(const char* sbase, unsigned voff, unsigned lds_dst) {
     unsigned keep;
     asm volatile(
@@ -255,15 +280,15 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                 xok |= ok ? (1u << i) : 0u;
             }
             const char* img_base = a.cur + (size_t)img * a.H * a.W * 32;
+            const unsigned long long xmask0 = __builtin_amdgcn_ballot_w64(xok & 1u), xmask1 = __builtin_amdgcn_ballot_w64((xok >> 1) & 1u),
+                                     xmask2 = __builtin_amdgcn_ballot_w64((xok >> 2) & 1u);
             auto x0_row = [&](int y, int slot) {      // image row y -> row slot `slot` of the x0 window (three pieces)
+                if (y < h) {
+                    glds16_row3_s(img_base + (size_t)y * a.W * 32, xoff[0], xoff[1], xoff[2], __builtin_amdgcn_readfirstlane(lds0 + slot * ROWB0), xmask0, xmask1, xmask2);
+                } else {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    const unsigned dst = lds0 + slot * ROWB0 + i * 1024;
-                    if (y < h) {
-                        if ((xok >> i) & 1u) glds16_s(img_base + (size_t)y * a.W * 32, xoff[i], __builtin_amdgcn_readfirstlane(dst));
-                    } else if (64 * i + lane < 144) {
-                        *reinterpret_cast<f32x4*>(smem + slot * ROWB0 + i * 1024 + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
-                    }
+                    for (int i = 0; i < 3; ++i)
+                        if (64 * i + lane < 144) *reinterpret_cast<f32x4*>(smem + slot * ROWB0 + i * 1024 + lane * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             };
             // ---- the windows start empty (zeros are the padding above the image and left / right of it)
