@@ -217,6 +217,14 @@ struct StripArgs {
     unsigned long long timeout_ticks;   // s_memrealtime ticks (100 MHz) a halo wait may take
 };
 
+// wave priorities (s_setprio): measured on the 4K frame, the DMA waves at 3 (as in the f32 fused kernel) cost 1.1 % against 0 or 1 --
+// their scalar instructions then win every issue slot they ask for on the SIMD they share with an MFMA wave
+#ifndef NESR_STRIP_DMA_PRIO
+#define NESR_STRIP_DMA_PRIO 0
+#endif
+#ifndef NESR_STRIP_MFMA_PRIO
+#define NESR_STRIP_MFMA_PRIO 0
+#endif
 #ifndef NESR_STRIP_ABL
 #define NESR_STRIP_ABL 0   // timing ablations (WRONG results): 1 no halo waits, 2 no MFMA, 4 no weight DMA, 8 no epilogues
 #endif
@@ -246,7 +254,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
     if (is_dma) {
         // ======================================================= DMA role.  Waves 0..2: the weight stream (six 1-KiB pieces each per
         // step); waves 0 / 1 also import the left / right halo column; wave 3: the x0 rows.
-        __builtin_amdgcn_s_setprio(3);
+        if (NESR_STRIP_DMA_PRIO) __builtin_amdgcn_s_setprio(NESR_STRIP_DMA_PRIO);
         const int d = wv;
         int wq7 = 4, wq78 = 4;     // weight stream position of q = 3 g + 4 (the first slot fetched after the barrier of step g)
         auto weight_task = [&](int q7, int q78, int kb) {
@@ -451,6 +459,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
     // of the step.  (Measured alternative: eight MFMA waves, two per SIMD, each half the couts -- same values, same time: the
     // pair of a SIMD finishes a step in ~1650 cycles against ~1300 for one wave doing all 54 MFMAs, because every pixel
     // fragment is then read twice; the step is bounded by MFMA time PLUS the time the fragment reads take to return.)
+    if (NESR_STRIP_MFMA_PRIO) __builtin_amdgcn_s_setprio(NESR_STRIP_MFMA_PRIO);
     const int j16 = lane & 15, g4 = lane >> 4;
     const unsigned lane_b = lds0 + (g4 >> 1) * CHB + j16 * 32 + (g4 & 1) * 16;
     const unsigned lane_a = lds0 + WRING + (g4 >> 1) * 1024 + (g4 & 1) * 512 + j16 * 16;
