@@ -650,8 +650,11 @@ __global__ __launch_bounds__(64 * (MW + DW), 3) void rdb_f16x2_kernel(RdbArgs a)
     // The two roles run separate loops over the same 52 steps (one s_barrier per step, one more before the first):
     // their register sets never coexist.
     if (is_dma) {
-#ifndef NESR_RDB_NOPRIO
-        __builtin_amdgcn_s_setprio(3);     // everything waits for what these four waves issue: they win the issue arbitration
+#ifdef NESR_RDB_DMAPRIO
+        // (round 2 raised these four waves' priority -- "everything waits for what they issue".  Measured in round 3, on this
+        // kernel and on rdb_bf16_strip_kernel: without it the frame is 0.5 % / 1.1 % faster; their scalar instructions otherwise
+        // win every issue slot they ask for on the SIMD they share with the MFMA waves.)
+        __builtin_amdgcn_s_setprio(NESR_RDB_DMAPRIO);
 #endif
         // ---- the plan (once per block) and the neighbours' progress words
         const unsigned lds_base = (unsigned)(size_t)(lds_char*)(smem);
