@@ -268,11 +268,21 @@ int nesr_shard_plan(int H, int W, int scale, int tile, int tile_pad, int nranks,
  * SuperResolutionPipeline._preprocess_image (nesr/nesr.py:674), on [C, H, W] u8 planes taken as ONE C-channel image (C = 1: the L
  * plane, C = 2: the a and b planes).  weights_dev: int32 table over the binned ("almost", >> 6) template distance,
  * round(M exp(-d / (h^2 C))) with OpenCV's fixed-point M, 0 below M / 1000 (imgproc.nl_means_weights builds it).  The Lab
- * conversions and CLAHE around it stay torch operations (imgproc.py).  Parity unpinned against cv2 (absent): checked against
+ * conversions around it stay torch operations (imgproc.py).  Parity unpinned against cv2 (absent): checked against
  * oracle/cv2_ref.py, a restatement of OpenCV's invoker.
  */
 int nesr_nl_means_u8(int device_id, const uint8_t* planes_dev, int C, int H, int W, int template_size, int search_size, const int* weights_dev, int nbins,
                      uint8_t* out_dev, void* hip_stream);
+
+/*
+ * `cv2.createCLAHE(clipLimit=2.0, tileGridSize=(8, 8)).apply(l)` of SuperResolutionPipeline._preprocess_image (nesr/nesr.py:680-684) on one
+ * [H, W] u8 plane: per-tile clipped and redistributed histograms -> look-up tables (the image counts as padded by BORDER_REFLECT_101 to
+ * a multiple of the grid -- both sides, only when one does not divide, as clahe.cpp does), every pixel the bilinear blend of the four
+ * surrounding tiles' tables.  lut_dev: grid_x * grid_y * 256 floats of device scratch.  Bit for bit imgproc.clahe_u8's torch
+ * composition; parity unpinned against cv2 (absent): checked against oracle/cv2_ref.py.
+ */
+int nesr_clahe_u8(int device_id, const uint8_t* gray_dev, int H, int W, double clip_limit, int grid_x, int grid_y, float* lut_dev, uint8_t* out_dev,
+                  void* hip_stream);
 
 /*
  * Single-layer entry (test hook for the per-layer parity tests): one 3x3 stride-1 zero-pad-1

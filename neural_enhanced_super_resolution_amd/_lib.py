@@ -58,6 +58,7 @@ SIGNATURES = {
     "nesr_shard_plan": (_c.c_int, [_c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.POINTER(_c.c_int), _c.c_int, _c.POINTER(_c.c_int),
                                    _c.POINTER(_c.c_int), _c.c_int, _c.POINTER(_c.c_int)]),
     "nesr_nl_means_u8": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_void_p, _c.c_void_p]),
+    "nesr_clahe_u8": (_c.c_int, [_c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_double, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p, _c.c_void_p]),
     "nesr_conv3x3": (_c.c_int, [_c.c_int, _c.c_int, _c.c_void_p, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p,
                                 _c.c_int, _c.c_int, _c.c_int, _c.c_void_p, _c.c_void_p]),
     "nesr_last_error": (_c.c_char_p, []),

@@ -91,4 +91,105 @@ hipError_t launch_nl_means(const uint8_t* src, int C, int H, int W, const int* l
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// cv2.createCLAHE(clipLimit = 2.0, tileGridSize = (8, 8)).apply(L) of SuperResolutionPipeline._preprocess_image (nesr/nesr.py:680-684),
+// restated from OpenCV's clahe.cpp (CLAHE_CalcLut_Body / CLAHE_Interpolation_Body; oracle/cv2_ref.py: clahe_u8; PARITY UNPINNED against
+// cv2).  Two launches: one workgroup per tile builds the tile's histogram in LDS (the image counts as padded by BORDER_REFLECT_101
+// to a multiple of the grid -- both sides, only when one of them does not divide), clips it, hands the clipped counts back out
+// (evenly, then one more at every `step`-th bin), integrates and scales to the look-up table; then every pixel blends the four
+// surrounding tiles' tables.  The float arithmetic is the torch composition's it replaces, operation by operation (single-precision
+// multiplies and adds that are never contracted, the division by the tile size as a multiplication by its float reciprocal, round
+// half to even), so the two agree bit for bit (tests/test_gpu_filters.py).  Byte work: one read of the plane per launch, one write.
+namespace {
+
+// single-precision operations that round by themselves: hipcc contracts a * b + c into an fma also when it is spelled
+// __fadd_rn(__fmul_rn(a, b), c) (and `#pragma clang fp contract(off)` does not reach those intrinsics), the torch
+// operations this replaces are separate kernels and never do
+__device__ __forceinline__ float mul_rn(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float add_rn(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float sub_rn(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+__global__ __launch_bounds__(256) void clahe_lut_kernel(const uint8_t* __restrict__ src, int h, int w, int th, int tw, int gx, int clip, float scale,
+                                                       float* __restrict__ lut) {
+    __shared__ int hist[256];
+    __shared__ int red[256];
+    const int t = threadIdx.x, tile = blockIdx.x, ty = tile / gx, tx = tile - ty * gx;
+    hist[t] = 0;
+    __syncthreads();
+    const int area = th * tw;
+    for (int i = t; i < area; i += 256) {
+        const int yy = ty * th + i / tw, xx = tx * tw + i % tw;
+        int sy = yy >= h ? 2 * (h - 1) - yy : yy, sx = xx >= w ? 2 * (w - 1) - xx : xx;      // BORDER_REFLECT_101 at the bottom / right
+        sy = sy < 0 ? 0 : (sy > h - 1 ? h - 1 : sy);
+        sx = sx < 0 ? 0 : (sx > w - 1 ? w - 1 : sx);
+        atomicAdd(&hist[src[(size_t)sy * w + sx]], 1);
+    }
+    __syncthreads();
+    int v = hist[t];
+    const int over = v > clip ? v - clip : 0;
+    v = v > clip ? clip : v;
+    red[t] = over;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (t < s2) red[t] += red[t + s2];
+        __syncthreads();
+    }
+    const int clipped = red[0];
+    __syncthreads();
+    const int batch = clipped / 256, residual = clipped - batch * 256;
+    v += batch;
+    if (residual > 0) {
+        int step = 256 / residual;
+        step = step < 1 ? 1 : step;
+        if (t % step == 0 && t / step < residual) v += 1;
+    }
+    // inclusive prefix sum over the 256 bins
+    red[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int add = t >= off ? red[t - off] : 0;
+        __syncthreads();
+        red[t] += add;
+        __syncthreads();
+    }
+    float q = rintf(mul_rn((float)red[t], scale));
+    q = q < 0.f ? 0.f : (q > 255.f ? 255.f : q);
+    lut[(size_t)tile * 256 + t] = q;
+}
+
+__global__ __launch_bounds__(256) void clahe_apply_kernel(const uint8_t* __restrict__ src, int h, int w, float inv_th, float inv_tw, int gx, int gy,
+                                                         const float* __restrict__ lut, uint8_t* __restrict__ dst) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float ys = sub_rn(mul_rn((float)y, inv_th), 0.5f), xs = sub_rn(mul_rn((float)x, inv_tw), 0.5f);
+    const float fy = floorf(ys), fx = floorf(xs);
+    const float ya = sub_rn(ys, fy), xa = sub_rn(xs, fx);
+    int ty1 = (int)fy, tx1 = (int)fx;
+    int ty2 = ty1 + 1, tx2 = tx1 + 1;
+    ty2 = ty2 < 0 ? 0 : (ty2 > gy - 1 ? gy - 1 : ty2);
+    tx2 = tx2 < 0 ? 0 : (tx2 > gx - 1 ? gx - 1 : tx2);
+    ty1 = ty1 < 0 ? 0 : (ty1 > gy - 1 ? gy - 1 : ty1);
+    tx1 = tx1 < 0 ? 0 : (tx1 > gx - 1 ? gx - 1 : tx1);
+    const int v = src[(size_t)y * w + x];
+    const float l11 = lut[((size_t)ty1 * gx + tx1) * 256 + v], l12 = lut[((size_t)ty1 * gx + tx2) * 256 + v];
+    const float l21 = lut[((size_t)ty2 * gx + tx1) * 256 + v], l22 = lut[((size_t)ty2 * gx + tx2) * 256 + v];
+    const float ixa = sub_rn(1.f, xa), iya = sub_rn(1.f, ya);
+    const float top = add_rn(mul_rn(l11, ixa), mul_rn(l12, xa)), bot = add_rn(mul_rn(l21, ixa), mul_rn(l22, xa));
+    float r = rintf(add_rn(mul_rn(top, iya), mul_rn(bot, ya)));
+    r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
+    dst[(size_t)y * w + x] = (uint8_t)r;
+}
+
+}  // namespace
+
+hipError_t launch_clahe(const uint8_t* src, int h, int w, int gx, int gy, int th, int tw, int clip, float scale, float inv_th, float inv_tw, float* lut,
+                        uint8_t* dst, hipStream_t s) {
+    hipLaunchKernelGGL(clahe_lut_kernel, dim3((unsigned)(gx * gy)), dim3(256), 0, s, src, h, w, th, tw, gx, clip, scale, lut);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(clahe_apply_kernel, dim3((unsigned)((w + 63) / 64), (unsigned)((h + 3) / 4)), dim3(256), 0, s, src, h, w, inv_th, inv_tw, gx, gy, lut, dst);
+    return hipGetLastError();
+}
+
 }  // namespace nesr

@@ -1235,6 +1235,22 @@ int nesr_nl_means_u8(int device_id, const uint8_t* planes_dev, int C, int H, int
     return NESR_OK;
 }
 
+int nesr_clahe_u8(int device_id, const uint8_t* gray_dev, int H, int W, double clip_limit, int grid_x, int grid_y, float* lut_dev, uint8_t* out_dev, void* stream) {
+    if (!gray_dev || !lut_dev || !out_dev) return fail(NESR_ERR_ARG, "null argument");
+    if (H < 1 || W < 1 || grid_x < 1 || grid_y < 1 || grid_x * grid_y > 4096 || !(clip_limit > 0.0)) return fail(NESR_ERR_ARG, "nesr_clahe_u8: non-empty image, grid and clip limit");
+    // clahe.cpp: the image is used as it is only when BOTH sides divide by the grid; otherwise both are padded
+    const int ph = (H % grid_y || W % grid_x) ? grid_y - H % grid_y : 0, pw = (H % grid_y || W % grid_x) ? grid_x - W % grid_x : 0;
+    const int th = (H + ph) / grid_y, tw = (W + pw) / grid_x;
+    const long long area = (long long)th * tw;
+    if (area > (1ll << 30)) return fail(NESR_ERR_ARG, "nesr_clahe_u8: tile too large");
+    int clip = (int)(clip_limit * (double)area / 256.0);
+    clip = clip < 1 ? 1 : clip;
+    HIP_TRY(hipSetDevice(device_id));
+    HIP_TRY(launch_clahe(gray_dev, H, W, grid_x, grid_y, th, tw, clip, (float)(255.0 / (double)area), 1.0f / (float)th, 1.0f / (float)tw, lut_dev, out_dev,
+                         static_cast<hipStream_t>(stream)));
+    return NESR_OK;
+}
+
 int nesr_conv3x3(int device_id, int dtype, const void* x_dev, int N, int Cin, int H, int W, const float* w_host,
                  const float* b_host, int Cout, int lrelu, int upsample, void* y_dev, void* stream) {
     if (!x_dev || !w_host || !b_host || !y_dev) return fail(NESR_ERR_ARG, "null argument");

@@ -226,6 +226,11 @@ hipError_t launch_paste_tiles(const TileIo& t, int n, int maxh, int maxw, hipStr
 // cv2.fastNlMeansDenoising (template 7, search 21) on [C][H][W] u8 planes taken as one C-channel image (imgproc.hip)
 hipError_t launch_nl_means(const uint8_t* src, int C, int H, int W, const int* lut, int nbins, int shift, uint8_t* dst, hipStream_t s);
 
+// cv2 CLAHE on one u8 plane (imgproc.hip): th x tw = tile size of the (virtually) padded image, clip = max(int(clipLimit * th * tw / 256), 1),
+// scale = 255 / (th * tw), inv_th / inv_tw = 1 / th, 1 / tw as floats; lut: gx * gy * 256 floats of device scratch
+hipError_t launch_clahe(const uint8_t* src, int h, int w, int gx, int gy, int th, int tw, int clip, float scale, float inv_th, float inv_tw, float* lut,
+                        uint8_t* dst, hipStream_t s);
+
 // feature map (channels [0,c)) -> planar f32 NCHW; used by the single-layer test hook
 hipError_t launch_nhwc_to_nchw(const void* src, int kind /* as PackArgs::bf16 */, Map map, int n, int c, int h, int w, float* dst, hipStream_t s);
 

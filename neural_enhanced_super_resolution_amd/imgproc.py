@@ -219,12 +219,27 @@ def clahe_tile_size(h, w, grid=(8, 8)):
     return (h + ph) // gy, (w + pw) // gx
 
 
-def clahe_u8(gray, clip_limit=2.0, grid=(8, 8)):
+def clahe_u8(gray, clip_limit=2.0, grid=(8, 8), use_hip=None):
     """cv2.createCLAHE(clipLimit, tileGridSize).apply(gray) on an HW uint8 tensor: the image is padded (REFLECT_101) to a
     multiple of the grid, every tile gets a clipped, redistributed histogram and a look-up table, and a pixel takes the
-    bilinear blend of the four surrounding tiles' tables."""
+    bilinear blend of the four surrounding tiles' tables.  On a ROCm device the two HIP kernels of csrc/imgproc.hip
+    (nesr_clahe_u8) unless use_hip=False selects the torch composition below -- the two agree bit for bit."""
     h, w = gray.shape
     gx, gy = grid
+    if use_hip is None:
+        use_hip = gray.device.type == "cuda" and gray.dtype == torch.uint8
+    if use_hip:
+        import ctypes
+        from . import _lib
+        src = gray.contiguous()
+        out = torch.empty_like(src)
+        lut = torch.empty((gy * gx * 256,), dtype=torch.float32, device=src.device)
+        index = src.device.index if src.device.index is not None else torch.cuda.current_device()
+        with torch.cuda.device(src.device):
+            stream = torch.cuda.current_stream(src.device).cuda_stream
+            _lib.check(_lib.load().nesr_clahe_u8(index, ctypes.c_void_p(src.data_ptr()), h, w, float(clip_limit), gx, gy, ctypes.c_void_p(lut.data_ptr()),
+                                                 ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(stream)), "nesr_clahe_u8")
+        return out
     # clahe.cpp: only when BOTH sides divide by the grid is the image used as it is; otherwise copyMakeBorder pads the bottom by
     # tilesY - h % tilesY and the right by tilesX - w % tilesX -- a side that does divide gets a whole extra tilesY / tilesX pixels
     ph, pw = (gy - h % gy, gx - w % gx) if (h % gy or w % gx) else (0, 0)

@@ -50,6 +50,28 @@ def test_nl_means_kernel_is_the_torch_composition_bit_for_bit(cuda_device, C, hw
         assert np.array_equal(got.cpu().numpy(), O.fast_nl_means_u8(planes.numpy(), h, 7, 21))
 
 
+@pytest.mark.parametrize("hw", [(64, 64), (64, 70), (50, 72), (37, 53), (9, 200), (512, 512), (1000, 1777)])
+@pytest.mark.parametrize("clip", [2.0, 40.0])
+def test_clahe_kernel_is_the_torch_composition_bit_for_bit(cuda_device, hw, clip):
+    """csrc/imgproc.hip (nesr_clahe_u8: histogram / table launch + blend launch) against the torch composition it replaces, on sides
+    that divide by the grid, sides of which exactly one divides (clahe.cpp pads BOTH then), odd sizes and tiles larger than 65535
+    pixels; against the oracle (numpy, oracle/cv2_ref.py) to one grey level (float32 vs float64 blend weights); nesr/nesr.py:680-684."""
+    from neural_enhanced_super_resolution_amd import imgproc as P
+    from oracle import cv2_ref as O
+    g = torch.Generator().manual_seed(5)
+    base = torch.randint(0, 256, (1, 1, hw[0] // 8 + 2, hw[1] // 8 + 2), generator=g).float()
+    img = torch.nn.functional.interpolate(base, size=hw, mode="bilinear", align_corners=False)[0, 0]
+    img = (img + torch.randint(-10, 11, img.shape, generator=g)).clamp(0, 255).to(torch.uint8)
+    dev = img.to(cuda_device)
+    got = P.clahe_u8(dev, clip, (8, 8))
+    want = P.clahe_u8(dev, clip, (8, 8), use_hip=False)
+    assert torch.equal(got, want), (got.int() - want.int()).abs().max().item()
+    assert not torch.equal(got, dev)
+    if hw[0] * hw[1] <= 300000:
+        dd = np.abs(got.cpu().numpy().astype(int) - O.clahe_u8(img.numpy(), clip, (8, 8)).astype(int))
+        assert dd.max() <= 1 and (dd > 0).mean() < 0.01
+
+
 def test_nl_means_kernel_time_on_a_large_plane(cuda_device):
     """2048 x 2048 (the second iteration's input of BASELINE.json configs[4]): seconds as torch operations, milliseconds as a kernel."""
     import time
