@@ -199,6 +199,17 @@ __device__ __forceinline__ f32x4 lrelu4(f32x4 v) {
     return o;
 }
 
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for_n(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+template <class F>
+__device__ __forceinline__ void static_for3(F&& f) {
+    f(std::integral_constant<int, 0>{});
+    f(std::integral_constant<int, 1>{});
+    f(std::integral_constant<int, 2>{});
+}
+
 struct StripArgs {
     const char* cur;          // the block's buffer: x0 = its chunks 0..3, channel-blocked bf16 [chunk][n*H*W pixels][16]
     long long chunk_bytes;
@@ -467,7 +478,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
     const float inv_s1 = 1.0f / a.s1;
     int aq = 0;                                     // ring slot of the current step's first tap column
     f32x4 acc[2][3][2];                             // [cout group (conv5) | 0][row][cout half]
-    f32x4 Bf[3][5], Af[3][2];                       // pixel fragments of tap column i (order 1, 0, 2) in buffer i; weight fragments [dy][cout half]
+    f32x4 Bf[3][5], Af[2][3][2];                       // pixel fragments of tap column i (order 1, 0, 2) in buffer i; weight fragments [dy][cout half]
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 2; ++c)
@@ -491,11 +502,11 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
         if (NESR_STRIP_ABL & 16) { asm volatile("" : "+v"(Bf[buf][k])); return; }
         Bf[buf][k] = *((lds_f32x4)(size_t)(ba[k] + dx * 32));
     };
-    auto load_a = [&](int dy, int slot) {
-        if (NESR_STRIP_ABL & 16) { asm volatile("" : "+v"(Af[dy][0]), "+v"(Af[dy][1])); return; }
+    auto load_a = [&](int buf, int dy, int slot) {      // buf, dy: compile-time constants at every call site
+        if (NESR_STRIP_ABL & 16) { asm volatile("" : "+v"(Af[buf][dy][0]), "+v"(Af[buf][dy][1])); return; }
         const unsigned wa = lane_a + slot * WSLOT + dy * 2048;
-        Af[dy][0] = *((lds_f32x4)(size_t)(wa));
-        Af[dy][1] = *((lds_f32x4)(size_t)(wa + 256));
+        Af[buf][dy][0] = *((lds_f32x4)(size_t)(wa));
+        Af[buf][dy][1] = *((lds_f32x4)(size_t)(wa + 256));
     };
     // One step: tap columns in the order 1, 0, 2 (column 1 touches no halo pixel, so its fragments may be requested before
     // the barrier behind which a freshly imported halo column becomes visible).  Column i's pixel fragments sit in buffer
@@ -509,12 +520,18 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
     // column.  conv5 runs the two cout groups of a chunk pair as steps (1, 2): the second one finds all three columns still in
     // the registers.  (The next step's fragment addresses -- scalar work + five adds -- are computed before the step's barrier, not
     // inside the MFMA stream: measured there, they cost the stream 350 cycles where they save 100 in front of the barrier.)
-    auto step_body = [&](auto Cc, auto Lc, const unsigned (&ba)[5], const unsigned (&nba)[5]) {
-        constexpr int CG = decltype(Cc)::value, LM = decltype(Lc)::value;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            int sl = aq + i + 1;
-            sl -= sl >= NWS ? NWS : 0;
+    // Weight fragments: two register sets, a tap column's in set (P + i) & 1 (P: parity of the step's first column; three columns a step,
+    // so it flips every step -- 26 steps a position: P is the parity of the step's number in the position, a compile-time constant
+    // of every call).  A set is re-requested right after a vertical tap's last MFMA for the column TWO ahead (this step's
+    // third, or the next step's first: 36 MFMAs of lead instead of 18); only the step's second column cannot be asked for that early
+    // -- its slot lands behind this step's barrier -- and is requested at the head of the first.
+    auto step_body = [&](auto Cc, auto Lc, auto Pc, const unsigned (&ba)[5], const unsigned (&nba)[5]) {
+        constexpr int CG = decltype(Cc)::value, LM = decltype(Lc)::value, P = decltype(Pc)::value;
+        static_for3([&](auto Ic) {
+            constexpr int i = decltype(Ic)::value, cb = (P + i) & 1;
+            int sl1 = aq + 1, sl2 = aq + i + 2;
+            sl1 -= sl1 >= NWS ? NWS : 0;
+            sl2 -= sl2 >= NWS ? NWS : 0;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 5; ++k) {
@@ -522,29 +539,31 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                 else if (i == 1) { if (LM != 2) load_b1(2, k, ba, 2); }
                 else if (LM != 1) load_b1(0, k, nba, 1);
             }
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
+            if constexpr (i == 0) {
+                load_a(cb ^ 1, 0, sl1); load_a(cb ^ 1, 1, sl1); load_a(cb ^ 1, 2, sl1);
+            }
+            static_for3([&](auto Dc) {
+                constexpr int dy = decltype(Dc)::value;
                 if (NESR_STRIP_ABL & 2) {
-                    asm volatile("" ::"v"(Af[dy][0]), "v"(Af[dy][1]), "v"(Bf[i][dy]), "v"(Bf[i][dy + 2]));
+                    asm volatile("" ::"v"(Af[cb][dy][0]), "v"(Af[cb][dy][1]), "v"(Bf[i][dy]), "v"(Bf[i][dy + 2]));
                 } else {
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        const bf16x8 wf = __builtin_bit_cast(bf16x8, Af[dy][mt]);
+                        const bf16x8 wf = __builtin_bit_cast(bf16x8, Af[cb][dy][mt]);
 #pragma unroll
                         for (int r = 0; r < 3; ++r)
                             acc[CG][r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, Bf[i][r + dy]), acc[CG][r][mt], 0, 0, 0);
                     }
                 }
-                load_a(dy, sl);
+                if constexpr (i < 2) load_a(cb, dy, sl2);
                 // pinned: the hipcc scheduler otherwise sinks every read to just before its first use and the MFMA stream
                 // stops at a short lgkmcnt wait a dozen times per step
                 __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+            });
+        });
         aq += 3;
         aq -= aq >= NWS ? NWS : 0;
     };
-
     for (int it = it0; it < it1; ++it) {
         const int4 item = a.items[2 * it], seg = a.items[2 * it + 1];
         const int img = item.x & 0xffff, s = item.y, h = item.z, w = item.w;
@@ -574,7 +593,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
 #pragma unroll
         for (int k = 0; k < 5; ++k) load_b1(0, k, ba, 1);
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) load_a(dy, aq);
+        for (int dy = 0; dy < 3; ++dy) load_a(0, dy, aq);
 
         for (int pos = pos0; pos < pos1; ++pos) {
             const unsigned tagbase = a.epoch + (unsigned)pos * 8u;
@@ -590,21 +609,23 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
             auto bias4 = [&](int boff, int mt) { return *reinterpret_cast<const f32x4*>(smem + BIASO + (boff + 16 * mt + 4 * g4) * 4); };
             auto layer = [&](auto Mc) {
                 constexpr int m = decltype(Mc)::value;
-                for (int p = 0; p <= m; ++p) {
+                constexpr int first = m == 1 ? 0 : m == 2 ? 2 : m == 3 ? 5 : 9;      // number of the layer's first step in the position
+                static_for_n<m + 1>([&](auto Pp) {
+                    constexpr int p = decltype(Pp)::value;
                     if (p < m) baddr_of(wbp, m, p + 1, nba);
                     else baddr_of(wbp, m + 1, 0, nba);
                     SSTAMP(wv, sidx, 0);
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
                     SSTAMP(wv, sidx, 1);
-                    step_body(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ba, nba);
+                    step_body(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, (first + p) & 1>{}, ba, nba);
                     SSTAMP(wv, sidx, 2);
 #if NESR_STRIP_ABL & 256
                     ++sidx;
 #endif
 #pragma unroll
                     for (int k = 0; k < 5; ++k) ba[k] = nba[k];
-                }
+                });
                 if (!(NESR_STRIP_ABL & 8)) {
                     // ---- x_m = lrelu(acc + bias): into this strip's window, edge columns also to the neighbours
                     // (the sums started from the bias: a bias read here would stand, with its LDS round trip, between the last
@@ -665,7 +686,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 SSTAMP(wv, sidx, 1);
-                step_body(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, ba, ba);   // the second cout group finds these pixels in the registers
+                step_body(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, ba, ba);   // the second cout group finds these pixels in the registers
                 SSTAMP(wv, sidx, 2);
 #if NESR_STRIP_ABL & 256
                 ++sidx;
@@ -687,7 +708,7 @@ __global__ __launch_bounds__(64 * (MW + DW), 2) void rdb_bf16_strip_kernel(Strip
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 SSTAMP(wv, sidx, 1);
-                step_body(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, ba, nba);
+                step_body(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, ba, nba);
                 SSTAMP(wv, sidx, 2);
 #if NESR_STRIP_ABL & 256
                 ++sidx;
